@@ -95,28 +95,29 @@ def theta(n, n_edges, seed):
 
 
 def randsparse(n, m, seed, c_edges=None, n_diag=2, n_off=8, r0=5, dense_c=False):
-    """cfg3b: C = max-cut Laplacian (or dense N(0,1)), m random sparse symmetric A_i with n_diag
-    diagonal + n_off off-diagonal entries, values N(0,1); b = A(R0 R0^T), R0 ~ N(0,1)/sqrt(n)
-    (n x r0) so the problem is feasible."""
+    """cfg3b: m random sparse symmetric A_i with n_diag diagonal + n_off off-diagonal entries, values
+    N(0,1); b = A(R0 R0^T), R0 ~ N(0,1)/sqrt(n) (n x r0) so the problem is feasible.  The objective
+    is C = L/4 + I/4 (graph Laplacian of a random graph plus a multiple of the identity; positive
+    definite, so min <C,X> over X >= 0 is bounded -- with C = -L/4 as in max-cut and no diagonal
+    constraints the SDP is unbounded and the reference diverges), or a dense PD matrix."""
     rng = np.random.default_rng(seed)
     ent = []
     if dense_c:
-        cm = rng.standard_normal((n, n))
-        cm = (cm + cm.T) / 2
+        g = rng.standard_normal((n, n))
+        cm = g @ g.T / n + np.eye(n)
         for i in range(n):
             for j in range(i, n):
-                ent.append((0, 1, i + 1, j + 1, float(cm[i, j])))
+                ent.append((0, 1, i + 1, j + 1, float(-cm[i, j])))
     else:
         ce = 6 * n if c_edges is None else c_edges
         edges = _rand_edges(n, ce, rng)
         deg = np.zeros(n)
         np.add.at(deg, edges[:, 0], 1.0)
         np.add.at(deg, edges[:, 1], 1.0)
-        for i in range(n):
-            if deg[i] != 0.0:
-                ent.append((0, 1, i + 1, i + 1, deg[i] / 4.0))
+        for i in range(n):  # F0 = -C  (the reader negates it back)
+            ent.append((0, 1, i + 1, i + 1, -(deg[i] / 4.0 + 0.25)))
         for i, j in edges.tolist():
-            ent.append((0, 1, i + 1, j + 1, -0.25))
+            ent.append((0, 1, i + 1, j + 1, 0.25))
     R0 = np.random.default_rng(seed + 1).standard_normal((n, r0)) / math.sqrt(n)
     b = np.zeros(m)
     for k in range(m):
