@@ -1,0 +1,329 @@
+"""ctypes mirror of the plain-C host (lorads_amd/csrc/host) and of its operator table.
+
+The table `Backend` is field-for-field `lrd_backend` (csrc/host/lorads_host.h), which itself is
+slot-for-slot the reference's `lorads_func` (src_semi/data/def_lorads_solver.h:109-127) plus the
+non-table calls on the path.  Tests read like the reference's own call sites:
+
+    be.init_constr(PAIR_RR); lag = be.alm_cal_grad(rho); be.lbfgs_direction(it); ...
+
+The product attaches ONLY the HIP table (`Session.attach_hip`), which raises if the HIP library is
+missing -- there is no CPU fallback here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+PAIR_RR, PAIR_UV = 0, 1
+MAT_R, MAT_U, MAT_V, MAT_GRAD = 0, 1, 2, 3
+VEC_LAMBDA, VEC_CONSTR_SUM, VEC_Q1, VEC_Q2 = 0, 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+
+
+class BackendStruct(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p),
+        ("name", C.c_char_p),
+        ("init_constr", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)),
+        ("alm_cal_grad", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, _dp)),
+        ("lbfgs_direction", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)),
+        ("alm_q12p12", C.CFUNCTYPE(C.c_int, C.c_void_p, _dp)),
+        ("alm_linesearch_coeffs", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, _dp)),
+        ("set_y_as_neg_grad", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+        ("alm_update_var", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)),
+        ("set_lbfgs_his_two", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)),
+        ("update_dimacs", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _dp)),
+        ("cal_obj", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _dp)),
+        ("admm_update_var", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, _ip)),
+        ("update_dual_var", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)),
+        ("cal_dual_obj", C.CFUNCTYPE(C.c_int, C.c_void_p, _dp)),
+        ("alm_to_admm", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+        ("average_uv_to_v", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+        ("scale_obj", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)),
+        ("resize_rank", C.CFUNCTYPE(C.c_int, C.c_void_p, _ip)),
+        ("set_mat", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, _dp)),
+        ("get_mat", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, _dp)),
+        ("set_vec", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _dp)),
+        ("get_vec", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _dp)),
+        ("set_allreduce", C.CFUNCTYPE(C.c_int, C.c_void_p, ALLREDUCE_FN, C.c_void_p)),
+        ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
+    ]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+class Backend:
+    """Pythonic view of one operator table (the one a Session owns after attach)."""
+
+    def __init__(self, struct_ptr, session):
+        self._s = struct_ptr.contents
+        self._session = session
+
+    @property
+    def name(self):
+        return self._s.name.decode()
+
+    def init_constr(self, pair):
+        _check(self._s.init_constr(self._s.ctx, pair), "init_constr")
+
+    def alm_cal_grad(self, rho):
+        v = C.c_double()
+        _check(self._s.alm_cal_grad(self._s.ctx, rho, C.byref(v)), "alm_cal_grad")
+        return v.value
+
+    def lbfgs_direction(self, inner_iter):
+        _check(self._s.lbfgs_direction(self._s.ctx, inner_iter), "lbfgs_direction")
+
+    def alm_q12p12(self):
+        p = (C.c_double * 2)()
+        _check(self._s.alm_q12p12(self._s.ctx, p), "alm_q12p12")
+        return p[0], p[1]
+
+    def alm_linesearch_coeffs(self, rho, p1, p2):
+        k = (C.c_double * 4)()
+        _check(self._s.alm_linesearch_coeffs(self._s.ctx, rho, p1, p2, k), "alm_linesearch_coeffs")
+        return [k[i] for i in range(4)]
+
+    def set_y_as_neg_grad(self):
+        _check(self._s.set_y_as_neg_grad(self._s.ctx), "set_y_as_neg_grad")
+
+    def alm_update_var(self, tau):
+        _check(self._s.alm_update_var(self._s.ctx, tau), "alm_update_var")
+
+    def set_lbfgs_his_two(self, tau):
+        _check(self._s.set_lbfgs_his_two(self._s.ctx, tau), "set_lbfgs_his_two")
+
+    def update_dimacs(self, pair):
+        v = C.c_double()
+        _check(self._s.update_dimacs(self._s.ctx, pair, C.byref(v)), "update_dimacs")
+        return v.value
+
+    def cal_obj(self, pair):
+        v = C.c_double()
+        _check(self._s.cal_obj(self._s.ctx, pair, C.byref(v)), "cal_obj")
+        return v.value
+
+    def admm_update_var(self, rho, cg_tol, cg_max_iter=800):
+        it = C.c_int()
+        _check(self._s.admm_update_var(self._s.ctx, rho, cg_tol, cg_max_iter, C.byref(it)), "admm_update_var")
+        return it.value
+
+    def update_dual_var(self, rho):
+        _check(self._s.update_dual_var(self._s.ctx, rho), "update_dual_var")
+
+    def cal_dual_obj(self):
+        v = C.c_double()
+        _check(self._s.cal_dual_obj(self._s.ctx, C.byref(v)), "cal_dual_obj")
+        return v.value
+
+    def alm_to_admm(self):
+        _check(self._s.alm_to_admm(self._s.ctx), "alm_to_admm")
+
+    def average_uv_to_v(self):
+        _check(self._s.average_uv_to_v(self._s.ctx), "average_uv_to_v")
+
+    def scale_obj(self, s):
+        _check(self._s.scale_obj(self._s.ctx, s), "scale_obj")
+
+    def resize_rank(self, new_rank):
+        arr = (C.c_int * len(new_rank))(*[int(x) for x in new_rank])
+        _check(self._s.resize_rank(self._s.ctx, arr), "resize_rank")
+        self._session._rank_override = [int(x) for x in new_rank]
+
+    def set_mat(self, which, blk, a):
+        """a: (n, r) array, any layout; sent column-major like the reference's matElem."""
+        a = np.asfortranarray(a, dtype=np.float64)
+        _check(self._s.set_mat(self._s.ctx, which, blk, a.ctypes.data_as(_dp)), "set_mat")
+
+    def get_mat(self, which, blk):
+        n, r = self._session.block_shape(blk)
+        out = np.empty((n, r), dtype=np.float64, order="F")
+        _check(self._s.get_mat(self._s.ctx, which, blk, out.ctypes.data_as(_dp)), "get_mat")
+        return out
+
+    def set_vec(self, which, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        _check(self._s.set_vec(self._s.ctx, which, v.ctypes.data_as(_dp)), "set_vec")
+
+    def get_vec(self, which):
+        out = np.empty(self._session.m, dtype=np.float64)
+        _check(self._s.get_vec(self._s.ctx, which, out.ctypes.data_as(_dp)), "get_vec")
+        return out
+
+
+def _bind(lib):
+    lib.lrd_session_open.restype = C.c_void_p
+    lib.lrd_session_open.argtypes = [C.c_char_p]
+    lib.lrd_session_from_triplets.restype = C.c_void_p
+    lib.lrd_session_from_triplets.argtypes = [C.c_int, _dp, C.c_int, _ip, C.c_int64, _ip, _ip, _ip, _ip, _dp]
+    lib.lrd_session_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    lib.lrd_session_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.lrd_session_problem.restype = C.c_void_p
+    lib.lrd_session_problem.argtypes = [C.c_void_p]
+    lib.lrd_session_backend.restype = C.POINTER(BackendStruct)
+    lib.lrd_session_backend.argtypes = [C.c_void_p]
+    lib.lrd_session_attach.argtypes = [C.c_void_p, C.POINTER(BackendStruct)]
+    lib.lrd_session_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.lrd_session_solve.argtypes = [C.c_void_p]
+    lib.lrd_session_alm.argtypes = [C.c_void_p]
+    lib.lrd_session_alm_to_admm.argtypes = [C.c_void_p]
+    lib.lrd_session_alm_to_admm.restype = None
+    lib.lrd_session_admm.argtypes = [C.c_void_p, C.c_int]
+    lib.lrd_session_results.argtypes = [C.c_void_p, _dp]
+    lib.lrd_session_block_info.argtypes = [C.c_void_p, C.c_int] + [_ip] * 8
+    lib.lrd_session_dims.argtypes = [C.c_void_p, _ip, _ip, _ip]
+    lib.lrd_session_start.restype = _dp
+    lib.lrd_session_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.lrd_session_current_rank.argtypes = [C.c_void_p, C.c_int]
+    lib.lrd_session_close.argtypes = [C.c_void_p]
+    lib.lrd_session_close.restype = None
+    lib.lrd_session_params_ptr = None
+    return lib
+
+
+_host_lib = None
+
+
+def host_lib():
+    """liblorads_host.so: the product's plain-C host, built by __graft_entry__.build()."""
+    global _host_lib
+    if _host_lib is None:
+        path = os.path.join(LIB_DIR, "liblorads_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: run `python __graft_entry__.py` (build()) first" % path)
+        _host_lib = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL))
+        _host_lib.lrd_hip_backend_create.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(BackendStruct)]
+    return _host_lib
+
+
+RESULT_KEYS = ["pObj", "dObj", "constrVio1", "pdGap", "alm_outer", "alm_inner", "alm_rho", "admm_iter", "cg_iter",
+               "admm_rho", "t_alm", "t_admm", "status", "admm_iters_first", "cg_iters_first", "constrVioInf"]
+
+
+class Session:
+    """One problem + parameter block + start point (+ solver once a table is attached)."""
+
+    def __init__(self, lib, handle):
+        if not handle:
+            raise RuntimeError("could not open the problem")
+        self.lib = lib
+        self.h = C.c_void_p(handle)
+        self.be = None
+        self._rank_override = None
+        self._keep = []
+
+    @classmethod
+    def open(cls, fname, lib=None):
+        lib = lib or host_lib()
+        return cls(lib, lib.lrd_session_open(os.fsencode(fname)))
+
+    @classmethod
+    def from_triplets(cls, m, b, dims, mat, blk, row, col, val, lib=None):
+        lib = lib or host_lib()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        dims = np.ascontiguousarray(dims, dtype=np.int32)
+        arrs = [np.ascontiguousarray(x, dtype=np.int32) for x in (mat, blk, row, col)]
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        h = lib.lrd_session_from_triplets(int(m), b.ctypes.data_as(_dp), len(dims), dims.ctypes.data_as(_ip),
+                                          len(val), *[a.ctypes.data_as(_ip) for a in arrs], val.ctypes.data_as(_dp))
+        return cls(lib, h)
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if self.lib.lrd_session_set_param(self.h, k.encode(), repr(v).encode() if not isinstance(v, str) else v.encode()):
+                raise KeyError("unknown parameter %s" % k)
+
+    def prepare(self, world=1, rank=0):
+        _check(self.lib.lrd_session_prepare(self.h, world, rank), "prepare")
+        m, nb, nbg = C.c_int(), C.c_int(), C.c_int()
+        self.lib.lrd_session_dims(self.h, C.byref(m), C.byref(nb), C.byref(nbg))
+        self.m, self.nblk, self.nblk_global = m.value, nb.value, nbg.value
+
+    def block_info(self, k):
+        v = [C.c_int() for _ in range(8)]
+        _check(self.lib.lrd_session_block_info(self.h, k, *[C.byref(x) for x in v]), "block_info")
+        keys = ["n", "rank", "nrow", "na", "nc", "np", "dense_mode", "cone_sparse"]
+        d = dict(zip(keys, [x.value for x in v]))
+        if self._rank_override is not None:
+            d["rank"] = self._rank_override[k]
+        elif self.be is not None:
+            d["rank"] = self.lib.lrd_session_current_rank(self.h, k)
+        return d
+
+    def block_shape(self, k):
+        d = self.block_info(k)
+        return d["n"], d["rank"]
+
+    def start_point(self, which, k):
+        d = self.block_info(k)
+        p = self.lib.lrd_session_start(self.h, which, k)
+        return np.ctypeslib.as_array(p, shape=(d["rank"], d["n"])).T.copy()
+
+    def problem_ptr(self):
+        return self.lib.lrd_session_problem(self.h)
+
+    def attach(self, struct):
+        _check(self.lib.lrd_session_attach(self.h, C.byref(struct)), "attach")
+        self.be = Backend(self.lib.lrd_session_backend(self.h), self)
+        return self.be
+
+    def attach_hip(self, lbfgs_len=2, libpath=None):
+        """Wire the operator table to the HIP C-ABI library (include/lorads_hip.h).  Raises when the
+        library or a GPU is missing: the product has no other backend."""
+        st = BackendStruct()
+        path = libpath or os.path.join(LIB_DIR, "liblorads_hip.so")
+        rc = self.lib.lrd_hip_backend_create(self.problem_ptr(), lbfgs_len, os.fsencode(path), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("HIP backend unavailable (code %d): %s -- the product has no CPU fallback" % (rc, path))
+        return self.attach(st)
+
+    def set_allreduce(self, fn):
+        """fn(ptr:int, count:int, on_device:bool) -> sums in place over ranks."""
+        def _cb(user, buf, count, on_device):
+            try:
+                fn(buf, count, bool(on_device))
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not unwind into C
+                print("allreduce hook failed:", e)
+                return 1
+        cb = ALLREDUCE_FN(_cb)
+        self._keep.append(cb)
+        _check(self.lib.lrd_session_set_allreduce(self.h, cb, None), "set_allreduce")
+
+    def solve(self):
+        _check(self.lib.lrd_session_solve(self.h), "solve")
+        return self.results()
+
+    def alm(self):
+        return self.lib.lrd_session_alm(self.h)
+
+    def alm_to_admm(self):
+        self.lib.lrd_session_alm_to_admm(self.h)
+
+    def admm(self, iter_ceiling):
+        return self.lib.lrd_session_admm(self.h, iter_ceiling)
+
+    def results(self):
+        out = (C.c_double * 16)()
+        _check(self.lib.lrd_session_results(self.h, out), "results")
+        return dict(zip(RESULT_KEYS, [out[i] for i in range(16)]))
+
+    def close(self):
+        if self.h:
+            self.lib.lrd_session_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -298,11 +298,21 @@ static int mode_trace(ctx_t *c, lorads_params *p, int n_alm, int n_admm, double 
     rec1("pObj_alm", S->pObjVal);
     rec1("dObj_alm", S->dObjVal);
 
-    /* hand-off: data/lorads_solver.c:968-983 (R -> V -> U) */
-    for (int k = 0; k < nb; ++k) {
-        size_t sz = sizeof(double) * (size_t)S->var->R[k]->nRows * S->var->R[k]->rank;
-        memcpy(S->var->V[k]->matElem, S->var->R[k]->matElem, sz);
-        memcpy(S->var->U[k]->matElem, S->var->V[k]->matElem, sz);
+    /* warm start for the ADMM part of the trace: the reference's own phase 1 from the current point
+     * (a cold ADMM start diverges and pins nothing); its result is dumped as an INPUT of the part */
+    {
+        double t0 = LUtilGetTimeStamp();
+        LORADS_ALMOptimize(p, S, &c->alm, p->maxALMIter, t0);
+        {
+            double rkw[64];
+            for (int k = 0; k < nb && k < 64; ++k) rkw[k] = S->var->R[k]->rank;
+            rec("rank_warm", rkw, nb); /* phase 1 may have grown the rank (AUG_RANK) */
+        }
+        dump_mats("R_warm_%d_%d", 0, S->var->R, nb);
+        rec("lambda_warm", S->var->dualVar, m);
+        LORADS_ALMtoADMM(S, p, &c->alm, &c->admm);
+        rho = c->admm.rho < p->rhoMax ? c->admm.rho : p->rhoMax;
+        rec1("admm_rho", rho);
     }
     /* ADMM prologue, lorads_admm.c:47-52 */
     S->cgIter = 0;

@@ -1,0 +1,63 @@
+"""Pins the CPU oracle (oracle/lorads_oracle.c + the host control flow) against golden vectors that
+were produced by the compiled REFERENCE (oracle/make_golden.py -> oracle/_ref).  CPU only."""
+import numpy as np
+import pytest
+
+from tests import common
+
+TRACE_NAMES = ["maxcut100", "theta30", "rand120", "blk4x60", "coupled3x70", "densec40", "matcomp60"]
+
+
+@pytest.mark.parametrize("name", TRACE_NAMES)
+def test_function_level_trace(name):
+    g = common.golden_trace(name)
+    s = common.oracle_session(common.instance_path(name))
+    try:
+        # branch decisions of the pre-solver must match the reference's
+        for k in range(s.nblk):
+            info = s.block_info(k)
+            assert info["rank"] == int(g["rank"][k])
+            assert info["cone_sparse"] == int(g["cone_is_sparse"][k])
+            assert info["dense_mode"] == int(g["wsum_is_dense"][k])
+        log = common.replay_trace(s, g, rtol=1e-10, resync=True)
+        assert len(log) > 50
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("name", ["maxcut100", "blk4x60"])
+def test_trace_without_resync(name):
+    """no state re-sync: errors may compound over the 8+3 steps but must stay tiny"""
+    g = common.golden_trace(name)
+    s = common.oracle_session(common.instance_path(name))
+    try:
+        common.replay_trace(s, g, rtol=1e-8, resync=False)
+    finally:
+        s.close()
+
+
+def _flags_to_params(flags):
+    return {flags[i][2:]: float(flags[i + 1]) if "." in flags[i + 1] or "e" in flags[i + 1] else int(flags[i + 1])
+            for i in range(0, len(flags), 2)}
+
+
+@pytest.mark.parametrize("idx", range(len(common.golden_solves())))
+def test_whole_solve(idx):
+    e = common.golden_solves()[idx]
+    s = common.oracle_session(common.instance_path(e["instance"]), **_flags_to_params(e["flags"]))
+    try:
+        r = s.solve()
+    finally:
+        s.close()
+    ref_gap = abs(e["pObj"] - e["dObj"]) / (1 + abs(e["pObj"]) + abs(e["dObj"]))
+    # both runs stop at the solver's own tolerance; objectives can only agree to that level
+    tol = max(1e-6, 5 * ref_gap)
+    assert abs(r["pObj"] - e["pObj"]) <= tol * (1 + abs(e["pObj"]))
+    assert abs(r["dObj"] - e["dObj"]) <= tol * (1 + abs(e["dObj"]))
+    assert r["constrVio1"] <= max(10 * e["err_constr_l1"], 1e-5)
+    if e["instance"] in ("maxcut100", "blk4x60", "maxcut800"):
+        # sparse-pattern instances: the restatement follows the reference iterate for iterate
+        assert int(r["alm_inner"]) == int(e["alm_inner"])
+        assert int(r["admm_iter"]) == int(e["admm_iter"])
+        assert int(r["cg_iter"]) == int(e["admm_cg_iter"])
+        assert abs(r["pObj"] - e["pObj"]) <= 1e-9 * (1 + abs(e["pObj"]))
