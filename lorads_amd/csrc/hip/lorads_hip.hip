@@ -1,0 +1,1285 @@
+// lorads_hip.hip -- MI355X (gfx950 / CDNA4) backend of the LoRADS per-iteration path.
+//
+// Hand-written HIP, FP64 throughout, wave64.  Implements the C ABI of include/lorads_hip.h; every
+// entry point cites there the reference function it replaces.  Nothing here falls back to a CPU
+// path: without a GPU lorads_hip_create fails.
+//
+// Data layout in HBM (per cone k, n x r factors):
+//   * factors R,U,V,Grad and the CG vectors are ROW-major n x r (ld = r): one factor row is one
+//     contiguous 8r-byte segment, so the row gathers of the sparse contractions are coalesced
+//     (the reference's column-major layout makes them stride-n level-1 BLAS calls).
+//     All cones are concatenated in one flat allocation per factor so that the L-BFGS vector
+//     operations run over sum_k n_k r_k in one launch.  The ABI movers transpose to/from the
+//     reference's column-major layout.
+//   * A_i: unique lower-triangular positions of all A_i of the cone ("A-pattern", PA entries) +
+//     CSR constraint -> (entry, value) + its transpose entry -> (constraint, value) + a full
+//     symmetric adjacency row -> (neighbour row, entry) for gather-form S*X (no atomics,
+//     bitwise reproducible).
+//   * C ∪ A "union pattern" (PU) with the same three structures, used by the RHS / gradient
+//     weighted-sum products (C + sum_i w_i A_i) X.
+//
+// Kernels (all HBM/L2-bound integer+FP64 gather work; bytes per unit in DESIGN.md):
+//   k_pairdots   T_e = X_p.Y_q + X_q.Y_p on a pattern            (reference LORADSUVt)
+//   k_cv_from_T  w_i = sum_k a_k T_e(k)                           (mul_inner_rk_double / coneAUV)
+//   k_sval       S_e = [C_e] + sum_(i,a) weight_i a               (sdpDataWSum / addObjCoeff)
+//   k_spmm       Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm)
+//   k_op_diag    fused operator when every A_i = a e_p e_p^T (Max-Cut): one pass
+//   k_cg_*       CG vector updates with device-resident scalars (CGSolve)
+//   misc         averaging, scatter-add, dual update, line-search dots, L-BFGS axpy/dot
+//
+// Reductions: every reducing kernel writes one partial per workgroup; the consumer re-sums the
+// partials (<= 2048) in a fixed order, so results do not depend on scheduling.  Wave-level sums use
+// 64-lane __shfl_xor butterflies.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lorads_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXPART = 4096; // capacity of one partial-sum slot
+
+thread_local std::string g_err;
+int fail(const char *what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+int fail_msg(const std::string &m) {
+    g_err = m;
+    return 1;
+}
+#define HC(call)                                          \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return fail(#call, e__);   \
+    } while (0)
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int LG>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = LG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over the 256-thread workgroup, result in every thread; sh = 4 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ double sum_partials(const double *part, int n, double *sh) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += TPB) v += part[i];
+    return block_sum(v, sh);
+}
+
+struct CGState {
+    double rr, bnorm, beta;
+    int done; // 0 running, 1 converged, 2 converged at the initial residual, 3 max iterations
+    int iter;
+    int nan;
+    int pad;
+};
+
+enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2 };
+enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
+enum { CHK_INIT = 0, CHK_ITER = 1, CHK_RESTART = 2 };
+enum { DIR_INIT = 0, DIR_BETA = 1, DIR_RESTART = 2 };
+
+// ------------------------------------------------------------------ kernels
+// T_e = X_p.Y_q + X_q.Y_p  (p != q)   |   X_p.Y_p  (p == q); LG lanes share one pattern entry
+template <int LG>
+__global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
+                                                  const double *__restrict__ X, const double *__restrict__ Y, int r,
+                                                  double *__restrict__ T, const CGState *st) {
+    if (st && st->done) return;
+    const int e = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
+    const bool act = e < ne;
+    const int p = act ? erow[e] : 0, q = act ? ecol[e] : 0;
+    const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
+    double s = 0.0;
+    if (p == q) {
+        for (int j = lane; j < r; j += LG) s += xp[j] * yq[j];
+    } else {
+        const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
+        for (int j = lane; j < r; j += LG) s += xp[j] * yq[j] + xq[j] * yp[j];
+    }
+    s = group_sum<LG>(s);
+    if (act && lane == 0) T[e] = s;
+}
+
+// partial of sum_e c_e * pairdot_e  (objective <C, sym(X Y^T)>); grid-stride so that the grid stays <= MAXPART
+template <int LG>
+__global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
+                                             const double *__restrict__ cval, const double *__restrict__ X,
+                                             const double *__restrict__ Y, int r, double *__restrict__ part) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x % LG, per = TPB / LG;
+    double s = 0.0; // every lane keeps its own slice; the block sum adds the slices
+    for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per) {
+        const int p = erow[e], q = ecol[e];
+        const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
+        double d = 0.0;
+        if (p == q) {
+            for (int j = lane; j < r; j += LG) d += xp[j] * yq[j];
+        } else {
+            const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
+            for (int j = lane; j < r; j += LG) d += xp[j] * yq[j] + xq[j] * yp[j];
+        }
+        s += d * cval[e];
+    }
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// w_i = scale * sum_k a_k T[e_k]; 8 lanes per constraint
+__global__ __launch_bounds__(TPB) void k_cv_from_T(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
+                                                   const double *__restrict__ a_val, const double *__restrict__ T,
+                                                   double scale, double *__restrict__ cv, const CGState *st) {
+    if (st && st->done) return;
+    const int i = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
+    const bool act = i < nrow;
+    double s = 0.0;
+    if (act)
+        for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) s += a_val[t] * T[a_e[t]];
+    s = group_sum<8>(s);
+    if (act && lane == 0) cv[i] = s * scale;
+}
+
+// vec[row_idx[i]] += alpha * cv[i]  (row_idx unique within one cone)
+__global__ void k_scatter_add(int nrow, const int *__restrict__ row_idx, const double *__restrict__ cv, double alpha,
+                              double *__restrict__ vec) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrow) vec[row_idx[i]] += alpha * cv[i];
+}
+
+struct WArgs {
+    const double *w;      // W_COMPACT: compact weights [nrow]
+    const double *csum;   // global m-vectors
+    const double *b;
+    const double *lambda;
+    const double *cv;     // compact [nrow]
+    const int *row_idx;
+    double rho;
+};
+__device__ __forceinline__ double weight_of(int mode, const WArgs &a, int i) {
+    if (mode == W_COMPACT) return a.w[i];
+    const int g = a.row_idx[i];
+    if (mode == W_ADMM) return ((a.csum[g] - a.b[g]) - a.cv[i]) * a.rho - a.lambda[g]; // lorads_admm.c:432-445
+    return (-a.lambda[g] - a.rho * a.b[g]) + a.rho * a.csum[g];                         // lorads_alm.c:22-26
+}
+// S_e = [cbase_e] + sum over the constraints touching e of weight_i * a
+__global__ __launch_bounds__(TPB) void k_sval(int ne, const int *__restrict__ e_ptr, const int *__restrict__ e_con,
+                                              const double *__restrict__ e_val, const double *__restrict__ cbase, int mode,
+                                              WArgs wa, double *__restrict__ S, const CGState *st) {
+    if (st && st->done) return;
+    const int e = blockIdx.x * TPB + threadIdx.x;
+    if (e >= ne) return;
+    double s = cbase ? cbase[e] : 0.0;
+    for (int t = e_ptr[e]; t < e_ptr[e + 1]; ++t) s += weight_of(mode, wa, e_con[t]) * e_val[t];
+    S[e] = s;
+}
+
+// Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction
+template <int LG>
+__global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj_ptr, const int *__restrict__ adj_col,
+                                              const int *__restrict__ adj_e, const double *__restrict__ S,
+                                              const double *__restrict__ X, int r, int mode, const double *__restrict__ xin,
+                                              const double *__restrict__ rhs, double rho, double *__restrict__ out,
+                                              double *__restrict__ part, const CGState *st) {
+    __shared__ double sh[4];
+    if (st && st->done) return;
+    const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
+    const bool act = row < n;
+    double acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+    if (act) {
+        const int t1 = adj_ptr[row + 1];
+        for (int t = adj_ptr[row]; t < t1; ++t) {
+            const double s = S[adj_e[t]];
+            const double *xq = X + (size_t)adj_col[t] * r;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int j = lane + c * LG;
+                if (j < r) acc[c] += s * xq[j];
+            }
+        }
+    }
+    double local = 0.0;
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = lane + c * LG;
+            if (j < r) {
+                const size_t idx = (size_t)row * r + j;
+                double v;
+                if (mode == OP_CG) { const double xi = xin[idx]; v = xi + acc[c]; local += xi * v; }
+                else if (mode == OP_RES) { v = rhs[idx] - (xin[idx] + acc[c]); local += v * v; }
+                else if (mode == OP_RHS) { v = X[idx] - acc[c] / rho; local += fabs(v); }
+                else { v = 2.0 * acc[c]; local += v * v; }
+                out[idx] = v;
+            }
+        }
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// Max-Cut-type cones (every A_i = a_i e_p e_p^T): the whole operator is row-local,
+//   out_p = x_p + g_p (x_p . V_p) V_p,  g_p = sum_i a_i^2  -> one pass over x and V
+template <int LG>
+__global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict__ g, const double *__restrict__ V, int r,
+                                                 int mode, const double *__restrict__ xin, const double *__restrict__ rhs,
+                                                 double *__restrict__ out, double *__restrict__ part, const CGState *st) {
+    __shared__ double sh[4];
+    if (st && st->done) return;
+    const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
+    const bool act = row < n;
+    double xv[8], vv[8], d = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int j = lane + c * LG;
+        const bool ok = act && j < r;
+        xv[c] = ok ? xin[(size_t)row * r + j] : 0.0;
+        vv[c] = ok ? V[(size_t)row * r + j] : 0.0;
+        d += xv[c] * vv[c];
+    }
+    d = group_sum<LG>(d) * (act ? g[row] : 0.0);
+    double local = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int j = lane + c * LG;
+        if (act && j < r) {
+            const size_t idx = (size_t)row * r + j;
+            double v = xv[c] + d * vv[c];
+            if (mode == OP_CG) local += xv[c] * v;
+            else { v = rhs[idx] - v; local += v * v; }
+            out[idx] = v;
+        }
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// x += alpha p, r -= alpha Q, partial ||r||^2; alpha = rr / (p.Q) from device scalars (lorads_cgs.c:181-189)
+__global__ __launch_bounds__(TPB) void k_cg_update(size_t len, const CGState *st, const double *__restrict__ part_pq, int npq,
+                                                   double *__restrict__ x, double *__restrict__ r,
+                                                   const double *__restrict__ p, const double *__restrict__ Q,
+                                                   double *__restrict__ part_rr) {
+    __shared__ double sh[4];
+    if (st->done) return;
+    const double pq = sum_partials(part_pq, npq, sh);
+    const double alpha = st->rr / pq;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
+        x[i] += alpha * p[i];
+        const double rv = r[i] - alpha * Q[i];
+        r[i] = rv;
+        local += rv * rv;
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+}
+
+// scalar bookkeeping of CGSolve, one workgroup
+__global__ __launch_bounds__(TPB) void k_cg_check(CGState *st, int kind, const double *__restrict__ part_a, int na,
+                                                  const double *__restrict__ part_b, int nb, double tol, int maxiter) {
+    __shared__ double sh[4];
+    if (kind != CHK_INIT && st->done) return;
+    const double a = sum_partials(part_a, na, sh);
+    double b = 0.0;
+    if (kind == CHK_INIT) b = sum_partials(part_b, nb, sh);
+    if (threadIdx.x != 0) return;
+    if (kind == CHK_INIT) { // lorads_cgs.c:115,149-160
+        st->rr = a;
+        st->bnorm = b;
+        st->beta = 0.0;
+        st->nan = 0;
+        if (sqrt(a) / b < tol) st->done = 2;
+        else { st->done = 0; st->iter = 0; }
+    } else if (kind == CHK_ITER) { // :189-194, :217-224
+        st->iter += 1;
+        if (a != a) st->nan = 1;
+        if (sqrt(a) / st->bnorm < tol) st->done = 1;
+        else if (st->iter >= maxiter) st->done = 3;
+        st->beta = a / st->rr;
+        st->rr = a;
+    } else { // restart: true residual, then beta = qTrNew/qTr = 1 (:195-221)
+        st->rr = a;
+        st->beta = 1.0;
+    }
+}
+
+__global__ void k_cg_dir(size_t len, const CGState *st, int kind, const double *__restrict__ r, double *__restrict__ p) {
+    if (st->done) return;
+    const double beta = st->beta;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+        const double rv = r[i];
+        p[i] = kind == DIR_INIT ? rv : (kind == DIR_RESTART ? rv + rv : rv + beta * p[i]);
+    }
+}
+
+// ---- small vector kernels
+__global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (u[i] + v[i]) / 2;
+}
+__global__ void k_axpy(size_t len, double a, const double *__restrict__ x, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+__global__ void k_axpy_dev(size_t len, const double *coef, const double *__restrict__ x, double *__restrict__ y) {
+    const double a = *coef;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+__global__ void k_scale_copy(size_t len, double a, const double *__restrict__ x, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i];
+}
+__global__ void k_scale(size_t len, double a, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) y[i] *= a;
+}
+// s = tau*D, y += G  (setlbfgsHisTwo)
+__global__ void k_his_two(size_t len, double tau, const double *__restrict__ D, const double *__restrict__ G,
+                          double *__restrict__ s, double *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+        s[i] = tau * D[i];
+        y[i] += G[i];
+    }
+}
+// D = -G when <D,G> >= 0 (LBFGSDirectionUseGrad)
+__global__ void k_use_grad(size_t len, const double *ip, const double *__restrict__ G, double *__restrict__ D) {
+    if (!(*ip >= 0)) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        D[i] = -G[i];
+}
+__global__ __launch_bounds__(TPB) void k_dot(size_t len, const double *__restrict__ x, const double *__restrict__ y,
+                                             double *__restrict__ part) {
+    __shared__ double sh[4];
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) local += x[i] * y[i];
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ part, int n, double *out) {
+    __shared__ double sh[4];
+    const double t = sum_partials(part, n, sh);
+    if (threadIdx.x == 0) *out = t;
+}
+enum { SOP_ALPHA = 0, SOP_W = 1, SOP_BETA = 2 };
+// scalar algebra of the two-loop recursion: sc = {dot, coef}; ring scalars in (alpha, beta)
+__global__ void k_scalar_op(int op, const double *dot, double *alpha, double *beta, double *coef) {
+    if (op == SOP_ALPHA) { *alpha = *beta * *dot; *coef = -1 * *alpha; }
+    else if (op == SOP_W) { *coef = *alpha - *beta * *dot; }
+    else { *beta = 1.0 / *dot; }
+}
+// err^2 partial of b - csum
+__global__ __launch_bounds__(TPB) void k_vio(int m, const double *__restrict__ b, const double *__restrict__ csum,
+                                             double *__restrict__ part) {
+    __shared__ double sh[4];
+    double local = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+        const double d = b[i] - csum[i];
+        local += d * d;
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// lambda += rho b - rho csum
+__global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
+                              double *__restrict__ lambda) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { double l = lambda[i] + rho * b[i]; lambda[i] = l + (-rho) * csum[i]; }
+}
+// csum += tau q1 + tau^2 q2
+__global__ void k_csum_step(int m, double tau, const double *__restrict__ q1, const double *__restrict__ q2,
+                            double *__restrict__ csum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { double c = csum[i] + tau * q1[i]; csum[i] = c + (tau * tau) * q2[i]; }
+}
+// five dots of the line search in one pass (single workgroup grid-stride; m is small)
+__global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const double *__restrict__ b,
+                                                    const double *__restrict__ csum, const double *__restrict__ lambda,
+                                                    const double *__restrict__ q1, const double *__restrict__ q2,
+                                                    double *__restrict__ part /* 5 x gridDim */) {
+    __shared__ double sh[4];
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+        const double q0 = (b[i] - csum[i]) + rinv * lambda[i];
+        const double a1 = q1[i], a2 = q2[i];
+        s[0] += a2 * a2; s[1] += a1 * a2; s[2] += a1 * a1; s[3] += q0 * a2; s[4] += q0 * a1;
+    }
+    for (int k = 0; k < 5; ++k) {
+        const double t = block_sum(s[k], sh);
+        if (threadIdx.x == 0) part[k * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T>
+int dalloc(T **p, size_t n) {
+    *p = nullptr;
+    HC(hipMalloc((void **)p, sizeof(T) * (n > 0 ? n : 1)));
+    return 0;
+}
+template <typename T>
+int upload(T **p, const std::vector<T> &v) {
+    if (dalloc(p, v.size())) return 1;
+    if (!v.empty()) HC(hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct Pattern {              // one symmetric sparsity pattern with everything the kernels need
+    int ne = 0;               // unique lower-tri entries
+    int *erow = nullptr, *ecol = nullptr;
+    int *e_ptr = nullptr, *e_con = nullptr; // entry -> (local constraint, value)
+    double *e_val = nullptr;
+    int *adj_ptr = nullptr, *adj_col = nullptr, *adj_e = nullptr; // row -> (neighbour, entry)
+    double *S = nullptr;      // values on the pattern
+    double *cbase = nullptr;  // C on the pattern (union pattern only)
+    void release() {
+        hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_val);
+        hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(S); hipFree(cbase);
+    }
+};
+
+struct Block {
+    int n = 0, r = 0, nrow = 0, na = 0, nc = 0;
+    size_t off = 0;           // offset of this cone in the flat factor arrays
+    int *row_idx = nullptr;
+    int *a_ptr = nullptr, *a_e = nullptr;  // constraint CSR over the A-pattern
+    double *a_val = nullptr;
+    Pattern pa, pu;
+    double *T = nullptr;      // pair dots on the A-pattern
+    double *cv = nullptr;     // constrVal[k], compact
+    double *wtmp = nullptr;   // compact weights inside the CG operator
+    int *c_row = nullptr, *c_col = nullptr;
+    double *c_val = nullptr;
+    std::vector<int> h_c_pu;  // position of each C entry in the union pattern (host)
+    std::vector<double> h_c_val;
+    bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
+    double *gdiag = nullptr;
+    int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
+    double bytes_mv = 0, bytes_cg = 0;
+};
+
+struct Ring {
+    double *s = nullptr, *y = nullptr;
+};
+
+} // namespace
+
+struct lorads_hip_ctx {
+    int m = 0, nb = 0, L = 2;
+    double b_nrm1 = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Block> blk;
+    size_t all_elem = 0;
+    double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
+    double *cr = nullptr, *cp = nullptr, *cQ = nullptr, *rhs = nullptr; // flat CG vectors
+    double *Dtmp = nullptr;
+    double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
+    double *part = nullptr;   // 8 x MAXPART partial sums
+    double *scal = nullptr;   // 64 device scalars
+    CGState *st = nullptr;
+    std::vector<Ring> ring;
+    double *ring_ab = nullptr; // [2L] alpha,beta per node
+    int head = 0;
+    lorads_hip_allreduce_fn ar = nullptr;
+    void *ar_user = nullptr;
+    // profiling
+    int prof = 0, prof_every = 8;
+    long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0;
+    double ms_samp = 0, ms_samp_spmm = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_mv, pend_sp;
+};
+
+namespace {
+
+inline int nblocks_for(size_t items, int per_block) { return (int)((items + per_block - 1) / per_block); }
+inline int grid1d(size_t len) {
+    size_t g = (len + TPB - 1) / TPB;
+    return (int)std::min<size_t>(std::max<size_t>(g, 1), MAXPART);
+}
+inline int lg_for(int r) { return r <= 64 ? 8 : (r <= 256 ? 32 : 64); }
+inline int spmm_rows_per_block(int r) { return TPB / lg_for(r); }
+
+double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * MAXPART; }
+
+// ---- pattern construction (host, once per context / rank change is independent of it)
+struct HostPattern {
+    std::vector<int> erow, ecol;
+    std::vector<int> e_ptr, e_con;
+    std::vector<double> e_val;
+    std::vector<int> adj_ptr, adj_col, adj_e;
+};
+
+// positions: list of (row,col) lower-tri; returns unique sorted list and index of each input position
+void unique_positions(const std::vector<std::pair<int, int>> &pos, std::vector<std::pair<int, int>> &uniq,
+                      std::vector<int> &index) {
+    std::vector<int> order(pos.size());
+    for (size_t i = 0; i < pos.size(); ++i) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        if (pos[a].second != pos[b].second) return pos[a].second < pos[b].second; // by column, then row
+        if (pos[a].first != pos[b].first) return pos[a].first < pos[b].first;
+        return a < b;
+    });
+    uniq.clear();
+    index.assign(pos.size(), -1);
+    for (size_t k = 0; k < order.size(); ++k) {
+        int i = order[k];
+        if (uniq.empty() || uniq.back() != pos[i]) uniq.push_back(pos[i]);
+        index[i] = (int)uniq.size() - 1;
+    }
+}
+
+void build_adjacency(int n, const std::vector<std::pair<int, int>> &uniq, HostPattern &hp) {
+    hp.erow.resize(uniq.size());
+    hp.ecol.resize(uniq.size());
+    std::vector<int> deg(n + 1, 0);
+    for (size_t e = 0; e < uniq.size(); ++e) {
+        hp.erow[e] = uniq[e].first;
+        hp.ecol[e] = uniq[e].second;
+        deg[uniq[e].first + 1]++;
+        if (uniq[e].first != uniq[e].second) deg[uniq[e].second + 1]++;
+    }
+    hp.adj_ptr.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) hp.adj_ptr[i + 1] = hp.adj_ptr[i] + deg[i + 1];
+    hp.adj_col.resize(hp.adj_ptr[n]);
+    hp.adj_e.resize(hp.adj_ptr[n]);
+    std::vector<int> fill(hp.adj_ptr.begin(), hp.adj_ptr.end() - 1);
+    for (size_t e = 0; e < uniq.size(); ++e) {
+        int p = uniq[e].first, q = uniq[e].second;
+        hp.adj_col[fill[p]] = q; hp.adj_e[fill[p]] = (int)e; fill[p]++;
+        if (p != q) { hp.adj_col[fill[q]] = p; hp.adj_e[fill[q]] = (int)e; fill[q]++; }
+    }
+    // neighbours in ascending row order: fixed summation order and better locality
+    for (int i = 0; i < n; ++i) {
+        int s = hp.adj_ptr[i], t = hp.adj_ptr[i + 1];
+        std::vector<std::pair<int, int>> tmp(t - s);
+        for (int k = s; k < t; ++k) tmp[k - s] = {hp.adj_col[k], hp.adj_e[k]};
+        std::sort(tmp.begin(), tmp.end());
+        for (int k = s; k < t; ++k) { hp.adj_col[k] = tmp[k - s].first; hp.adj_e[k] = tmp[k - s].second; }
+    }
+}
+
+// transpose of the constraint CSR over pattern entries
+void build_transpose(int ne, int nrow, const int *a_ptr, const std::vector<int> &a_e, const double *a_val, HostPattern &hp) {
+    hp.e_ptr.assign(ne + 1, 0);
+    int na = a_ptr[nrow];
+    for (int t = 0; t < na; ++t) hp.e_ptr[a_e[t] + 1]++;
+    for (int e = 0; e < ne; ++e) hp.e_ptr[e + 1] += hp.e_ptr[e];
+    hp.e_con.resize(na);
+    hp.e_val.resize(na);
+    std::vector<int> fill(hp.e_ptr.begin(), hp.e_ptr.end() - 1);
+    for (int i = 0; i < nrow; ++i)
+        for (int t = a_ptr[i]; t < a_ptr[i + 1]; ++t) {
+            int e = a_e[t];
+            hp.e_con[fill[e]] = i;
+            hp.e_val[fill[e]] = a_val[t];
+            fill[e]++;
+        }
+}
+
+int upload_pattern(Pattern &P, const HostPattern &hp, const std::vector<double> *cbase) {
+    P.ne = (int)hp.erow.size();
+    if (upload(&P.erow, hp.erow) || upload(&P.ecol, hp.ecol) || upload(&P.e_ptr, hp.e_ptr) || upload(&P.e_con, hp.e_con) ||
+        upload(&P.e_val, hp.e_val) || upload(&P.adj_ptr, hp.adj_ptr) || upload(&P.adj_col, hp.adj_col) ||
+        upload(&P.adj_e, hp.adj_e))
+        return 1;
+    if (dalloc(&P.S, (size_t)P.ne)) return 1;
+    if (cbase && upload(&P.cbase, *cbase)) return 1;
+    return 0;
+}
+
+int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
+    B.n = hb.n; B.r = hb.rank; B.nrow = hb.nrow; B.na = hb.a_ptr[hb.nrow]; B.nc = hb.c_nnz;
+    if (B.r > 512) return fail_msg("rank > 512 is not supported by the row kernels");
+    if (nblocks_for((size_t)B.n, spmm_rows_per_block(B.r)) > MAXPART) return fail_msg("cone dimension too large for the partial-sum slots of this build");
+    std::vector<std::pair<int, int>> posA(B.na), posU;
+    for (int t = 0; t < B.na; ++t) {
+        if (hb.a_row[t] < hb.a_col[t] || hb.a_col[t] < 0 || hb.a_row[t] >= hb.n) return fail_msg("A entry out of range / not lower-triangular");
+        posA[t] = {hb.a_row[t], hb.a_col[t]};
+    }
+    for (int t = 0; t < B.nc; ++t)
+        if (hb.c_row[t] < hb.c_col[t] || hb.c_col[t] < 0 || hb.c_row[t] >= hb.n) return fail_msg("C entry out of range / not lower-triangular");
+    for (int i = 0; i < hb.nrow; ++i)
+        if (hb.row_idx[i] < 0 || hb.row_idx[i] >= c->m) return fail_msg("constraint index out of range");
+    // A-pattern
+    std::vector<std::pair<int, int>> uniqA;
+    std::vector<int> a_e;
+    unique_positions(posA, uniqA, a_e);
+    HostPattern hpA;
+    build_adjacency(B.n, uniqA, hpA);
+    build_transpose((int)uniqA.size(), hb.nrow, hb.a_ptr, a_e, hb.a_val, hpA);
+    if (upload_pattern(B.pa, hpA, nullptr)) return 1;
+    // union pattern C ∪ A
+    posU = posA;
+    for (int t = 0; t < B.nc; ++t) posU.push_back({hb.c_row[t], hb.c_col[t]});
+    std::vector<std::pair<int, int>> uniqU;
+    std::vector<int> u_idx;
+    unique_positions(posU, uniqU, u_idx);
+    HostPattern hpU;
+    build_adjacency(B.n, uniqU, hpU);
+    std::vector<int> a_eU(u_idx.begin(), u_idx.begin() + B.na);
+    build_transpose((int)uniqU.size(), hb.nrow, hb.a_ptr, a_eU, hb.a_val, hpU);
+    std::vector<double> cbase(uniqU.size(), 0.0);
+    B.h_c_pu.assign(u_idx.begin() + B.na, u_idx.end());
+    B.h_c_val.assign(hb.c_val, hb.c_val + B.nc);
+    for (int t = 0; t < B.nc; ++t) cbase[B.h_c_pu[t]] += hb.c_val[t];
+    if (upload_pattern(B.pu, hpU, &cbase)) return 1;
+    // constraint CSR + misc
+    std::vector<int> v_rowidx(hb.row_idx, hb.row_idx + hb.nrow), v_aptr(hb.a_ptr, hb.a_ptr + hb.nrow + 1);
+    std::vector<double> v_aval(hb.a_val, hb.a_val + B.na);
+    std::vector<int> v_crow(hb.c_row, hb.c_row + B.nc), v_ccol(hb.c_col, hb.c_col + B.nc);
+    if (upload(&B.row_idx, v_rowidx) || upload(&B.a_ptr, v_aptr) || upload(&B.a_e, a_e) || upload(&B.a_val, v_aval) ||
+        upload(&B.c_row, v_crow) || upload(&B.c_col, v_ccol) || upload(&B.c_val, B.h_c_val))
+        return 1;
+    if (dalloc(&B.T, (size_t)B.pa.ne) || dalloc(&B.cv, (size_t)B.nrow) || dalloc(&B.wtmp, (size_t)B.nrow)) return 1;
+    HC(hipMemset(B.cv, 0, sizeof(double) * (size_t)std::max(B.nrow, 1)));
+    // Max-Cut fast path
+    bool diag = B.nrow > 0;
+    std::vector<double> g(B.n, 0.0);
+    for (int i = 0; i < hb.nrow && diag; ++i) {
+        if (hb.a_ptr[i + 1] - hb.a_ptr[i] != 1) { diag = false; break; }
+        int t = hb.a_ptr[i];
+        if (hb.a_row[t] != hb.a_col[t]) { diag = false; break; }
+        g[hb.a_row[t]] += hb.a_val[t] * hb.a_val[t];
+    }
+    B.diag_only = diag;
+    if (diag && upload(&B.gdiag, g)) return 1;
+    return 0;
+}
+
+void block_bytes(Block &B) {
+    double F = 8.0 * B.n * B.r;
+    B.bytes_mv = 4 * F + 32.0 * B.na + 16.0 * B.nrow;
+    B.bytes_cg = B.bytes_mv + 9 * F;
+}
+
+int alloc_factors(lorads_hip_ctx *c) {
+    c->all_elem = 0;
+    for (auto &B : c->blk) { B.off = c->all_elem; c->all_elem += (size_t)B.n * B.r; block_bytes(B); }
+    size_t n = c->all_elem;
+    double **arrs[] = {&c->R, &c->U, &c->V, &c->G, &c->cr, &c->cp, &c->cQ, &c->rhs, &c->Dtmp};
+    for (auto a : arrs) {
+        if (dalloc(a, n)) return 1;
+        HC(hipMemset(*a, 0, sizeof(double) * std::max<size_t>(n, 1)));
+    }
+    c->ring.resize(c->L);
+    for (auto &nd : c->ring) {
+        if (dalloc(&nd.s, n) || dalloc(&nd.y, n)) return 1;
+        HC(hipMemset(nd.s, 0, sizeof(double) * std::max<size_t>(n, 1)));
+        HC(hipMemset(nd.y, 0, sizeof(double) * std::max<size_t>(n, 1)));
+    }
+    HC(hipDeviceSynchronize());
+    return 0;
+}
+void free_factors(lorads_hip_ctx *c) {
+    double *arrs[] = {c->R, c->U, c->V, c->G, c->cr, c->cp, c->cQ, c->rhs, c->Dtmp};
+    for (auto a : arrs) hipFree(a);
+    for (auto &nd : c->ring) { hipFree(nd.s); hipFree(nd.y); }
+    c->ring.clear();
+}
+
+double *mat_base(lorads_hip_ctx *c, int which) {
+    switch (which) {
+    case LORADS_HIP_MAT_R: return c->R;
+    case LORADS_HIP_MAT_U: return c->U;
+    case LORADS_HIP_MAT_V: return c->V;
+    case LORADS_HIP_MAT_GRAD: return c->G;
+    }
+    return nullptr;
+}
+double *vec_base(lorads_hip_ctx *c, int which) {
+    switch (which) {
+    case LORADS_HIP_VEC_LAMBDA: return c->lambda;
+    case LORADS_HIP_VEC_CONSTR_SUM: return c->csum;
+    case LORADS_HIP_VEC_Q1: return c->q12;
+    case LORADS_HIP_VEC_Q2: return c->q12 + c->m;
+    }
+    return nullptr;
+}
+
+int allreduce_dev(lorads_hip_ctx *c, double *buf, int count) {
+    if (!c->ar) return 0;
+    HC(hipStreamSynchronize(c->stream));
+    if (c->ar(c->ar_user, buf, count, 1)) return fail_msg("allreduce hook failed");
+    return 0;
+}
+
+// ---- launch helpers
+template <int LG>
+void launch_pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, const CGState *st) {
+    if (P.ne == 0) return;
+    hipLaunchKernelGGL(k_pairdots<LG>, dim3(nblocks_for((size_t)P.ne, TPB / LG)), dim3(TPB), 0, c->stream, P.ne, P.erow, P.ecol, X,
+                       Y, r, T, st);
+}
+void pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, const CGState *st) {
+    switch (lg_for(r)) {
+    case 8: launch_pairdots<8>(c, P, X, Y, r, T, st); break;
+    case 32: launch_pairdots<32>(c, P, X, Y, r, T, st); break;
+    default: launch_pairdots<64>(c, P, X, Y, r, T, st); break;
+    }
+}
+// returns the number of partials written
+template <int LG>
+int launch_spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin,
+                const double *rhs, double rho, double *out, double *part, const CGState *st) {
+    int g = nblocks_for((size_t)B.n, TPB / LG);
+    hipLaunchKernelGGL(k_spmm<LG>, dim3(g), dim3(TPB), 0, c->stream, B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin,
+                       rhs, rho, out, part, st);
+    return g;
+}
+int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin, const double *rhs,
+         double rho, double *out, double *part, const CGState *st) {
+    switch (lg_for(B.r)) {
+    case 8: return launch_spmm<8>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
+    case 32: return launch_spmm<32>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
+    default: return launch_spmm<64>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
+    }
+}
+template <int LG>
+int launch_op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs,
+                   double *out, double *part, const CGState *st) {
+    int g = nblocks_for((size_t)B.n, TPB / LG);
+    hipLaunchKernelGGL(k_op_diag<LG>, dim3(g), dim3(TPB), 0, c->stream, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, st);
+    return g;
+}
+template <int LG>
+int launch_obj(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part) {
+    int g = std::min(nblocks_for((size_t)B.nc, TPB / LG), MAXPART);
+    hipLaunchKernelGGL(k_obj<LG>, dim3(g), dim3(TPB), 0, c->stream, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part);
+    return g;
+}
+int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part) {
+    if (B.nc == 0) return 0;
+    switch (lg_for(B.r)) {
+    case 8: return launch_obj<8>(c, B, X, Y, part);
+    case 32: return launch_obj<32>(c, B, X, Y, part);
+    default: return launch_obj<64>(c, B, X, Y, part);
+    }
+}
+
+// cv = scale * A_k(sym(X Y^T))   (LORADSInitConstrVal, lorads_alg_common.c:71-76)
+void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, double scale, double *cv, const CGState *st) {
+    if (B.nrow == 0) return;
+    pairdots(c, B.pa, X, Y, B.r, B.T, st);
+    hipLaunchKernelGGL(k_cv_from_T, dim3(nblocks_for((size_t)B.nrow, TPB / 8)), dim3(TPB), 0, c->stream, B.nrow, B.a_ptr, B.a_e,
+                       B.a_val, B.T, scale, cv, st);
+}
+void scatter_add(lorads_hip_ctx *c, const Block &B, const double *cv, double alpha, double *vec) {
+    if (B.nrow == 0) return;
+    hipLaunchKernelGGL(k_scatter_add, dim3(nblocks_for((size_t)B.nrow, TPB)), dim3(TPB), 0, c->stream, B.nrow, B.row_idx, cv, alpha,
+                       vec);
+}
+void sval(lorads_hip_ctx *c, const Block &B, const Pattern &P, bool with_c, int mode, const WArgs &wa, const CGState *st) {
+    if (P.ne == 0) return;
+    hipLaunchKernelGGL(k_sval, dim3(nblocks_for((size_t)P.ne, TPB)), dim3(TPB), 0, c->stream, P.ne, P.e_ptr, P.e_con, P.e_val,
+                       with_c ? P.cbase : nullptr, mode, wa, P.S, st);
+}
+
+// one application of the CG operator  out = epilogue(x + (sum_i <A_i, sym(x V^T)> A_i) V)
+// (linSysProduct, lorads_admm.c:376-391); returns #partials in `part`
+int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x, int mode, const double *rhs, double *out,
+                   double *part) {
+    const bool samp = c->prof && (c->n_matvec % c->prof_every == 0);
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (samp) {
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, c->stream);
+    }
+    int g;
+    if (B.diag_only) {
+        switch (lg_for(B.r)) {
+        case 8: g = launch_op_diag<8>(c, B, V, mode, x, rhs, out, part, c->st); break;
+        case 32: g = launch_op_diag<32>(c, B, V, mode, x, rhs, out, part, c->st); break;
+        default: g = launch_op_diag<64>(c, B, V, mode, x, rhs, out, part, c->st); break;
+        }
+    } else {
+        constr_val(c, B, x, V, 1.0, B.wtmp, c->st);
+        WArgs wa{};
+        wa.w = B.wtmp;
+        sval(c, B, B.pa, false, W_COMPACT, wa, c->st);
+        if (samp) { hipEventCreate(&e2); hipEventRecord(e2, c->stream); }
+        g = spmm(c, B, B.pa, V, mode, x, rhs, 0.0, out, part, c->st);
+    }
+    if (samp) {
+        hipEventRecord(e1, c->stream);
+        c->pend_mv.push_back({e0, e1});
+        if (e2) c->pend_sp.push_back({e2, e1});
+    }
+    c->n_matvec++;
+    return g;
+}
+
+void drain_events(lorads_hip_ctx *c) {
+    for (auto &pr : c->pend_mv) {
+        float ms = 0;
+        hipEventSynchronize(pr.second);
+        hipEventElapsedTime(&ms, pr.first, pr.second);
+        c->ms_samp += ms; c->n_samp++;
+    }
+    for (auto &pr : c->pend_sp) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, pr.first, pr.second);
+        c->ms_samp_spmm += ms; c->n_samp_spmm++;
+        hipEventDestroy(pr.first);
+    }
+    for (auto &pr : c->pend_mv) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    c->pend_mv.clear();
+    c->pend_sp.clear();
+}
+
+// LORADSUpdateSDPVarOne (lorads_admm.c:428-480): rhs = V - (C + sum_i M1_i A_i) V / rho, then CG on x
+int update_one(lorads_hip_ctx *c, Block &B, double *x, const double *V, double rho, double tol, int maxit, int *iters) {
+    const size_t len = (size_t)B.n * B.r;
+    double *r = c->cr + B.off, *p = c->cp + B.off, *Q = c->cQ + B.off, *rhs = c->rhs + B.off;
+    double *pA = part_slot(c, 0), *pB = part_slot(c, 1), *pC = part_slot(c, 2);
+    WArgs wa{};
+    wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.cv = B.cv; wa.row_idx = B.row_idx; wa.rho = rho;
+    HC(hipMemsetAsync(c->st, 0, sizeof(CGState), c->stream));
+    sval(c, B, B.pu, true, W_ADMM, wa, nullptr);
+    int nb1 = spmm(c, B, B.pu, V, OP_RHS, nullptr, nullptr, rho, rhs, pB, nullptr); // ||rhs||_1 partials
+    // initial residual (lorads_cgs.c:149-160)
+    int na = apply_operator(c, B, V, x, OP_RES, rhs, r, pA);
+    hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_INIT, pA, na, pB, nb1, tol, maxit);
+    const int gv = grid1d(len);
+    hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_INIT, r, p);
+    CGState h{};
+    int k = 0;
+    int chunk = std::max(2, std::min(B.cg_iter_last > 0 ? B.cg_iter_last : 8, 32));
+    for (;;) {
+        for (int t = 0; t < chunk && k < maxit; ++t, ++k) {
+            int npq = apply_operator(c, B, V, p, OP_CG, nullptr, Q, pA);
+            hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, pA, npq, x, r, p, Q, pC);
+            hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_ITER, pC, gv, nullptr, 0, tol, maxit);
+            if (k % 20 == 0) { // restart with the true residual (lorads_cgs.c:195-211), including k = 0
+                int nr = apply_operator(c, B, V, x, OP_RES, rhs, r, pA);
+                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_RESTART, pA, nr, nullptr, 0, tol,
+                                   maxit);
+                hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_RESTART, r, p);
+            } else {
+                hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_BETA, r, p);
+            }
+        }
+        HC(hipMemcpyAsync(&h, c->st, sizeof(CGState), hipMemcpyDeviceToHost, c->stream));
+        HC(hipStreamSynchronize(c->stream));
+        if (h.done || k >= maxit) break;
+        chunk = std::max(2, std::min(chunk, 16));
+    }
+    if (h.nan) fprintf(stderr, "lorads_hip: NaN residual in CG (block n=%d)\n", B.n);
+    if (h.done != 2) B.cg_iter_last = h.iter; // an immediate exit leaves the stale count (reference quirk)
+    *iters = B.cg_iter_last;
+    c->n_cg_it += (h.done == 2 ? 0 : h.iter);
+    c->n_solves++;
+    return 0;
+}
+
+int refresh_constr_all(lorads_hip_ctx *c, const double *X, const double *Y) {
+    HC(hipMemsetAsync(c->csum, 0, sizeof(double) * (size_t)(c->m + 2), c->stream));
+    for (auto &B : c->blk) {
+        constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, nullptr);
+        scatter_add(c, B, B.cv, 1.0, c->csum);
+    }
+    return 0;
+}
+
+int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) {
+    HC(hipMemcpyAsync(out, c->scal + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// flat dot -> device scalar slot (+ cross-rank sum)
+int dot_to_slot(lorads_hip_ctx *c, const double *x, const double *y, int slot) {
+    int g = grid1d(c->all_elem);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(TPB), 0, c->stream, c->all_elem, x, y, part_slot(c, 3));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 3), g, c->scal + slot);
+    return allreduce_dev(c, c->scal + slot, 1);
+}
+
+int objective(lorads_hip_ctx *c, const double *X, const double *Y, int slot) {
+    // sum over cones of <C_k, sym(X_k Y_k^T)> -> scal[slot] (local part)
+    HC(hipMemsetAsync(c->scal + slot, 0, sizeof(double), c->stream));
+    for (auto &B : c->blk) {
+        int g = obj_partials(c, B, X + B.off, Y + B.off, part_slot(c, 4));
+        if (g == 0) continue;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 4), g, c->scal + 32);
+        hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, 1.0, c->scal + 32, c->scal + slot);
+    }
+    return 0;
+}
+
+} // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+const char *lorads_hip_last_error(void) { return g_err.c_str(); }
+
+int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail_msg("no HIP device: the MI355X backend has no CPU fallback");
+    if (prob->device >= 0) HC(hipSetDevice(prob->device));
+    lorads_hip_ctx *c = new lorads_hip_ctx();
+    c->m = prob->m; c->nb = prob->nblocks; c->L = std::max(prob->lbfgs_len, 1); c->b_nrm1 = prob->b_nrm1;
+    HC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->blk.resize(c->nb);
+    for (int k = 0; k < c->nb; ++k)
+        if (build_block(c, c->blk[k], prob->blocks[k])) { lorads_hip_destroy(c); return 1; }
+    if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
+    std::vector<double> hb(prob->b, prob->b + c->m);
+    if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
+        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)8 * MAXPART) || dalloc(&c->scal, 64) ||
+        dalloc(&c->st, 1) || dalloc(&c->ring_ab, (size_t)2 * c->L)) {
+        lorads_hip_destroy(c);
+        return 1;
+    }
+    HC(hipMemset(c->lambda, 0, sizeof(double) * (size_t)std::max(c->m, 1)));
+    HC(hipMemset(c->csum, 0, sizeof(double) * (size_t)(c->m + 2)));
+    HC(hipMemset(c->q12, 0, sizeof(double) * (size_t)(2 * c->m + 2)));
+    HC(hipMemset(c->scal, 0, sizeof(double) * 64));
+    HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
+    HC(hipMemset(c->st, 0, sizeof(CGState)));
+    HC(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+void lorads_hip_destroy(lorads_hip_ctx *c) {
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drain_events(c);
+    for (auto &B : c->blk) {
+        B.pa.release(); B.pu.release();
+        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.cv); hipFree(B.wtmp);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag);
+    }
+    free_factors(c);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->scal); hipFree(c->st);
+    hipFree(c->ring_ab);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lorads_hip_sync(lorads_hip_ctx *c) {
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lorads_hip_set_allreduce(lorads_hip_ctx *c, lorads_hip_allreduce_fn fn, void *user) {
+    c->ar = fn;
+    c->ar_user = user;
+    return 0;
+}
+
+int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
+    const double *X = pair == LORADS_HIP_PAIR_RR ? c->R : c->U, *Y = pair == LORADS_HIP_PAIR_RR ? c->R : c->V;
+    if (refresh_constr_all(c, X, Y)) return 1;
+    return allreduce_dev(c, c->csum, c->m);
+}
+
+int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
+    HC(hipMemsetAsync(c->scal + 1, 0, sizeof(double), c->stream));
+    for (auto &B : c->blk) {
+        WArgs wa{};
+        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
+        sval(c, B, B.pu, true, W_ALM, wa, nullptr);
+        int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), nullptr);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 0), g, c->scal + 32);
+        hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, 1.0, c->scal + 32, c->scal + 1);
+    }
+    if (allreduce_dev(c, c->scal + 1, 1)) return 1;
+    return read_scalars(c, 1, 1, lag);
+}
+
+int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
+    const size_t n = c->all_elem;
+    const int gv = grid1d(n);
+    double *D = c->U;
+    if (inner == 0) {
+        hipLaunchKernelGGL(k_scale_copy, dim3(gv), dim3(TPB), 0, c->stream, n, -1.0, c->G, D);
+    } else {
+        double *q = c->Dtmp;
+        HC(hipMemcpyAsync(q, c->G, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        const int nn = inner <= c->L - 1 ? inner : c->L;
+        int node = (c->head - 1 + c->L) % c->L;
+        double *dot = c->scal + 8, *coef = c->scal + 9;
+        for (int t = 0; t < nn; ++t) {
+            if (dot_to_slot(c, c->ring[node].s, q, 8)) return 1;
+            hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_ALPHA, dot, c->ring_ab + 2 * node,
+                               c->ring_ab + 2 * node + 1, coef);
+            hipLaunchKernelGGL(k_axpy_dev, dim3(gv), dim3(TPB), 0, c->stream, n, coef, c->ring[node].y, q);
+            node = (node - 1 + c->L) % c->L;
+        }
+        node = (node + 1) % c->L;
+        for (int t = 0; t < nn; ++t) {
+            if (dot_to_slot(c, c->ring[node].y, q, 8)) return 1;
+            hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_W, dot, c->ring_ab + 2 * node,
+                               c->ring_ab + 2 * node + 1, coef);
+            hipLaunchKernelGGL(k_axpy_dev, dim3(gv), dim3(TPB), 0, c->stream, n, coef, c->ring[node].s, q);
+            node = (node + 1) % c->L;
+        }
+        hipLaunchKernelGGL(k_scale_copy, dim3(gv), dim3(TPB), 0, c->stream, n, -1.0, q, D);
+    }
+    if (dot_to_slot(c, D, c->G, 10)) return 1;
+    hipLaunchKernelGGL(k_use_grad, dim3(gv), dim3(TPB), 0, c->stream, n, c->scal + 10, c->G, D);
+    return 0;
+}
+
+int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
+    const int m = c->m;
+    HC(hipMemsetAsync(c->q12, 0, sizeof(double) * (size_t)(2 * m + 2), c->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        const double *X = pass == 0 ? c->R : c->U; // D lives in U
+        const double scale = pass == 0 ? 2.0 : 1.0;
+        for (auto &B : c->blk) {
+            constr_val(c, B, X + B.off, c->U + B.off, 1.0, B.cv, nullptr);
+            scatter_add(c, B, B.cv, scale, c->q12 + (size_t)pass * m);
+            int g = obj_partials(c, B, X + B.off, c->U + B.off, part_slot(c, 4));
+            if (g == 0) continue;
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 4), g, c->scal + 32);
+            hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, scale, c->scal + 32, c->q12 + 2 * m + pass);
+        }
+    }
+    if (allreduce_dev(c, c->q12, 2 * m + 2)) return 1;
+    HC(hipMemcpyAsync(p12, c->q12 + 2 * m, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
+    const int g = std::min(grid1d((size_t)c->m), 64);
+    hipLaunchKernelGGL(k_linesearch, dim3(g), dim3(TPB), 0, c->stream, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12,
+                       c->q12 + c->m, part_slot(c, 5));
+    for (int t = 0; t < 5; ++t)
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 5) + (size_t)t * g, g, c->scal + 16 + t);
+    double s[5];
+    if (read_scalars(c, 16, 5, s)) return 1;
+    k[0] = rho * s[0] / 2;              // rho ||q2||^2 / 2
+    k[1] = rho * s[1];                  // rho q1.q2
+    k[2] = p2 - rho * s[3] + rho * s[2] / 2;
+    k[3] = p1 - rho * s[4];
+    return 0;
+}
+
+int lorads_hip_set_y_as_neg_grad(lorads_hip_ctx *c) {
+    hipLaunchKernelGGL(k_scale_copy, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, -1.0, c->G,
+                       c->ring[c->head].y);
+    return 0;
+}
+
+int lorads_hip_alm_update_var(lorads_hip_ctx *c, double tau) {
+    hipLaunchKernelGGL(k_axpy, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, tau, c->U, c->R);
+    hipLaunchKernelGGL(k_csum_step, dim3(nblocks_for((size_t)c->m, TPB)), dim3(TPB), 0, c->stream, c->m, tau, c->q12, c->q12 + c->m,
+                       c->csum);
+    return 0;
+}
+
+int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
+    Ring &h = c->ring[c->head];
+    hipLaunchKernelGGL(k_his_two, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, tau, c->U, c->G, h.s, h.y);
+    if (dot_to_slot(c, h.y, h.s, 8)) return 1;
+    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 8, c->ring_ab + 2 * c->head,
+                       c->ring_ab + 2 * c->head + 1, c->scal + 9);
+    c->head = (c->head + 1) % c->L;
+    return 0;
+}
+
+int lorads_hip_update_dimacs(lorads_hip_ctx *c, int32_t pair, double *err1) {
+    if (pair == LORADS_HIP_PAIR_UV)
+        hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
+    if (refresh_constr_all(c, c->R, c->R)) return 1;
+    if (allreduce_dev(c, c->csum, c->m)) return 1;
+    const int g = std::min(grid1d((size_t)c->m), 256);
+    hipLaunchKernelGGL(k_vio, dim3(g), dim3(TPB), 0, c->stream, c->m, c->b, c->csum, part_slot(c, 6));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 6), g, c->scal + 2);
+    double s;
+    if (read_scalars(c, 2, 1, &s)) return 1;
+    *err1 = std::sqrt(s) / (1 + c->b_nrm1);
+    return 0;
+}
+
+int lorads_hip_cal_obj(lorads_hip_ctx *c, int32_t pair, double *pobj) {
+    if (pair == LORADS_HIP_PAIR_UV)
+        hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
+    if (objective(c, c->R, c->R, 3)) return 1;
+    if (allreduce_dev(c, c->scal + 3, 1)) return 1;
+    return read_scalars(c, 3, 1, pobj);
+}
+
+int lorads_hip_admm_update_var(lorads_hip_ctx *c, double rho, double tol, int32_t maxit, int32_t *iters) {
+    int tot = 0;
+    for (auto &B : c->blk) {
+        double *U = c->U + B.off, *V = c->V + B.off;
+        for (int half = 0; half < 2; ++half) {
+            int it = 0;
+            if (update_one(c, B, half == 0 ? U : V, half == 0 ? V : U, rho, tol, maxit, &it)) return 1;
+            tot += it;
+            // running sum bookkeeping of LORADSUpdateSDPVar (lorads_alg_common.c:199-203)
+            scatter_add(c, B, B.cv, -1.0, c->csum);
+            constr_val(c, B, U, V, 1.0, B.cv, nullptr);
+            scatter_add(c, B, B.cv, 1.0, c->csum);
+        }
+    }
+    *iters = tot;
+    return 0;
+}
+
+int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
+    hipLaunchKernelGGL(k_dual_update, dim3(nblocks_for((size_t)c->m, TPB)), dim3(TPB), 0, c->stream, c->m, rho, c->b, c->csum,
+                       c->lambda);
+    return 0;
+}
+
+int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
+    const int g = std::min(grid1d((size_t)c->m), 256);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(TPB), 0, c->stream, (size_t)c->m, c->b, c->lambda, part_slot(c, 7));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 7), g, c->scal + 4);
+    return read_scalars(c, 4, 1, dobj);
+}
+
+int lorads_hip_alm_to_admm(lorads_hip_ctx *c) {
+    HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
+    HC(hipMemcpyAsync(c->U, c->V, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
+    hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
+    HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
+    for (auto &B : c->blk) {
+        if (B.nc) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)B.nc)), dim3(TPB), 0, c->stream, (size_t)B.nc, s, B.c_val);
+        if (B.pu.ne) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)B.pu.ne)), dim3(TPB), 0, c->stream, (size_t)B.pu.ne, s, B.pu.cbase);
+    }
+    if (c->m) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)c->m)), dim3(TPB), 0, c->stream, (size_t)c->m, s, c->lambda);
+    return 0;
+}
+
+int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double *cm) {
+    double *base = mat_base(c, which);
+    if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
+    Block &B = c->blk[k];
+    std::vector<double> rm((size_t)B.n * B.r);
+    for (int j = 0; j < B.r; ++j)
+        for (int i = 0; i < B.n; ++i) rm[(size_t)i * B.r + j] = cm[(size_t)j * B.n + i];
+    HC(hipMemcpyAsync(base + B.off, rm.data(), sizeof(double) * rm.size(), hipMemcpyHostToDevice, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lorads_hip_get_mat(lorads_hip_ctx *c, int32_t which, int32_t k, double *cm) {
+    double *base = mat_base(c, which);
+    if (!base || k < 0 || k >= c->nb) return fail_msg("get_mat: bad argument");
+    Block &B = c->blk[k];
+    std::vector<double> rm((size_t)B.n * B.r);
+    HC(hipMemcpyAsync(rm.data(), base + B.off, sizeof(double) * rm.size(), hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < B.r; ++j)
+        for (int i = 0; i < B.n; ++i) cm[(size_t)j * B.n + i] = rm[(size_t)i * B.r + j];
+    return 0;
+}
+
+int lorads_hip_set_vec(lorads_hip_ctx *c, int32_t which, const double *v) {
+    double *d = vec_base(c, which);
+    if (!d) return fail_msg("set_vec: bad argument");
+    HC(hipMemcpyAsync(d, v, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lorads_hip_get_vec(lorads_hip_ctx *c, int32_t which, double *v) {
+    double *d = vec_base(c, which);
+    if (!d) return fail_msg("get_vec: bad argument");
+    HC(hipMemcpyAsync(v, d, sizeof(double) * (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
+    // AUG_RANK (data/lorads_solver.c:806-906): keep the old columns, new columns = 1/sqrt(k) on their
+    // leading diagonal (lpRandomDiag :776-786), clear L-BFGS history and CG workspaces
+    std::vector<std::vector<double>> keep[4];
+    int whichs[4] = {LORADS_HIP_MAT_R, LORADS_HIP_MAT_U, LORADS_HIP_MAT_V, LORADS_HIP_MAT_GRAD};
+    for (int a = 0; a < 4; ++a) {
+        keep[a].resize(c->nb);
+        for (int k = 0; k < c->nb; ++k) {
+            Block &B = c->blk[k];
+            if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
+            std::vector<double> oldm((size_t)B.n * B.r);
+            if (lorads_hip_get_mat(c, whichs[a], k, oldm.data())) return 1;
+            std::vector<double> nw((size_t)B.n * nr[k], 0.0);
+            std::copy(oldm.begin(), oldm.end(), nw.begin());
+            int aug = nr[k] - B.r, rr = std::min(B.n, aug);
+            for (int i = 0; i < rr; ++i) nw[(size_t)B.n * B.r + (size_t)i * B.n + i] = 1 / std::sqrt((double)rr);
+            keep[a][k] = std::move(nw);
+        }
+    }
+    free_factors(c);
+    for (int k = 0; k < c->nb; ++k) { c->blk[k].r = nr[k]; }
+    if (alloc_factors(c)) return 1;
+    for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < c->nb; ++k)
+            if (lorads_hip_set_mat(c, whichs[a], k, keep[a][k].data())) return 1;
+    HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
+    return 0;
+}
+
+int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
+    HC(hipStreamSynchronize(c->stream));
+    drain_events(c);
+    c->prof = enable;
+    c->prof_every = std::max(1, every);
+    c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = 0;
+    c->ms_samp = c->ms_samp_spmm = 0;
+    return 0;
+}
+
+int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
+    HC(hipStreamSynchronize(c->stream));
+    drain_events(c);
+    s[0] = (double)c->n_matvec;
+    s[1] = c->n_samp ? c->ms_samp / c->n_samp * c->n_matvec : 0.0;
+    s[2] = (double)c->n_cg_it;
+    s[3] = (double)c->n_solves;
+    s[4] = (double)c->n_samp;
+    s[5] = c->ms_samp;
+    s[6] = (double)c->n_samp_spmm;
+    s[7] = c->ms_samp_spmm;
+    return 0;
+}
+
+int lorads_hip_algorithmic_bytes(lorads_hip_ctx *c, int32_t k, double *mv, double *cg) {
+    if (k < 0 || k >= c->nb) return fail_msg("bad block");
+    *mv = c->blk[k].bytes_mv;
+    *cg = c->blk[k].bytes_cg;
+    return 0;
+}
+
+} // extern "C"
