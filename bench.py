@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/s (+ inner CG iterations/s) of the low-rank ADMM hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[2]): one dense-cone block n = 20000, r = 40
+(--timesLogRank 4.0), m = 5000 random sparse A_i (2 diagonal + 8 off-diagonal entries each),
+C = L/4 + I/4 of a 120000-edge random graph, b = A(R0 R0^T); generated with fixed seeds by
+lorads_amd/instances.py.  N GPUs = N such blocks (block-diagonal SDP, block-separable constraints),
+one block per GPU, ONE all-reduce of the shared m-vector per ADMM iteration (weak scaling).
+
+A step = one ADMM iteration = admmUpdateVar (U- and V-solve by CG) + objective + dual objective +
+DIMACS refresh + dual update (reference lorads_admm.c:76-81,120), with rho fixed at its hand-off
+value and the CG tolerance min(1e-2 * err1, 1e-8) refreshed every iteration.  The factors come from
+the solver's own phase 1 run on the GPU beforehand (untimed): --phase1Tol 1e-2 as in BASELINE.md.
+Everything is resident in HBM when the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_instance(name, path):
+    from lorads_amd import instances
+    if not os.path.exists(path):
+        t0 = time.time()
+        instances.write_sdpa(instances.NAMED[name](), path + ".tmp")
+        os.replace(path + ".tmp", path)
+        log("generated %s in %.1fs" % (name, time.time() - t0))
+    return path
+
+
+def replicate_blocks(path, nblk, out):
+    """N identical blocks, constraint i of block k -> index k*m + i (block-separable)."""
+    if os.path.exists(out):
+        return out
+    with open(path) as f:
+        lines = f.read().split("\n")
+    m = int(lines[0])
+    n = int(lines[2].split()[0])
+    b = lines[3].split()
+    ents = [ln.split() for ln in lines[4:] if ln.strip()]
+    with open(out + ".tmp", "w") as f:
+        f.write("%d\n%d\n%s\n%s\n" % (m * nblk, nblk, " ".join([str(n)] * nblk), " ".join(b * nblk)))
+        for k in range(nblk):
+            for e in ents:
+                mat = int(e[0])
+                f.write("%d %d %s %s %s\n" % (mat if mat == 0 else mat + k * m, k + 1, e[2], e[3], e[4]))
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def admm_steps(be, host, rho, err1, steps):
+    """`steps` ADMM iterations through the operator table; returns (err1, cg_iters, pobj, dobj)."""
+    cg = 0
+    pobj = dobj = 0.0
+    for _ in range(steps):
+        tol = min(err1 * 1e-2, 1e-8)
+        cg += be.admm_update_var(rho, tol, 800)
+        pobj = be.cal_obj(host.PAIR_UV)
+        dobj = be.cal_dual_obj()
+        err1 = be.update_dimacs(host.PAIR_UV)
+        be.update_dual_var(rho)
+    return err1, cg, pobj, dobj
+
+
+def make_allreduce(dist, torch, device):
+    class _Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def fn(ptr, count, on_device):
+        if on_device:
+            t = torch.as_tensor(_Dev(ptr, count), device=device)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        else:
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
+            t = torch.from_numpy(a.copy()).to(device)
+            dist.all_reduce(t)
+            a[:] = t.cpu().numpy()
+    return fn
+
+
+def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
+    """Times the CPU path on the host cores, rank 0 / N = 1 only: the compiled reference
+    (oracle/_ref, kind "reference") when it is present, else the plain-C restatement (kind "port")."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    if os.path.exists(drv):
+        try:
+            its = 2
+            for attempt in range(2):
+                t0 = time.time()
+                r = subprocess.run([drv, path, "admmbench", "-", "--timesLogRank", repr(tlr), "--rho", repr(rho), "--uv", state_file,
+                                    "--nADMM", str(its)], env=env, capture_output=True, text=True, timeout=900)
+                wall = time.time() - t0
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("@@REF_ADMM_BENCH")]
+                if r.returncode != 0 or not line:
+                    raise RuntimeError("ref_driver failed: " + r.stderr[-500:])
+                kv = dict(x.split("=") for x in line[0].split()[1:])
+                sec = float(kv["seconds"])
+                if attempt == 0 and sec < budget_s / 3:
+                    its = int(max(2, min(64, its * budget_s / 2 / max(sec, 1e-3))))
+                    continue
+                break
+            log_fn("cpu reference: %d ADMM its in %.2fs (setup+run wall %.1fs), %s CG its" % (its, sec, wall, kv["cg_iters"]))
+            return {"value": its / sec, "unit": "ADMM iters/s", "cores": 1, "kind": "reference",
+                    "cg_iters_per_s": int(kv["cg_iters"]) / sec,
+                    "sample": "%d ADMM iterations (%s CG iterations) of the same workload from the same start state, "
+                              "compiled reference (MKL sequential, 1 thread) on the host" % (its, kv["cg_iters"])}
+        except Exception as e:  # noqa: BLE001
+            log_fn("reference baseline unavailable (%s); timing the C restatement" % e)
+    from lorads_amd import host
+    from tests import common
+    s = common.oracle_session(path, timesLogRank=tlr)
+    try:
+        raw = np.fromfile(state_file, dtype=np.float64)
+        n, r = s.block_shape(0)
+        U = raw[:n * r].reshape(r, n).T
+        V = raw[n * r:2 * n * r].reshape(r, n).T
+        lam = raw[2 * n * r:2 * n * r + s.m]
+        s.be.set_mat(host.MAT_U, 0, U)
+        s.be.set_mat(host.MAT_V, 0, V)
+        s.be.set_vec(host.VEC_LAMBDA, lam)
+        s.be.init_constr(host.PAIR_UV)
+        s.be.cal_obj(host.PAIR_UV)
+        err1 = s.be.update_dimacs(host.PAIR_UV)
+        its, t0 = 0, time.time()
+        cg = 0
+        while time.time() - t0 < budget_s / 2 and its < 64:
+            err1, c, _, _ = admm_steps(s.be, host, rho, err1, 1)
+            cg += c
+            its += 1
+        sec = time.time() - t0
+    finally:
+        s.close()
+    return {"value": its / sec, "unit": "ADMM iters/s", "cores": 1, "kind": "port", "cg_iters_per_s": cg / sec,
+            "sample": "%d ADMM iterations (%d CG iterations) of the same workload from the same start state, "
+                      "plain-C restatement (oracle/) on 1 host core" % (its, cg)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="rand20000", help="rand20000 (headline, cfg3b) | maxcut20000 (cfg3a) | any NAMED")
+    ap.add_argument("--times-log-rank", type=float, default=4.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--sample-every", type=int, default=4)
+    a = ap.parse_args()
+
+    import torch
+    import __graft_entry__
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    if rank == 0:
+        __graft_entry__.build()
+    if dist:
+        dist.barrier()
+    from lorads_amd import host
+
+    base = build_instance(a.workload, "/tmp/lorads_bench_%s.dat-s" % a.workload) if rank == 0 else None
+    if dist:
+        dist.barrier()
+    base = "/tmp/lorads_bench_%s.dat-s" % a.workload
+    path = base
+    if world > 1:
+        path = "/tmp/lorads_bench_%s_x%d.dat-s" % (a.workload, world)
+        if rank == 0:
+            replicate_blocks(base, world, path)
+        dist.barrier()
+
+    s = host.Session.open(path)
+    s.set_params(verbose=0, timesLogRank=a.times_log_rank, phase1Tol=1e-2, reoptLevel=0)
+    s.prepare(world, rank)
+    s.attach_hip()
+    if dist:
+        s.set_allreduce(make_allreduce(dist, torch, device))
+    be = s.be
+    info = s.block_info(0)
+    # ---- untimed set-up: phase 1 on the GPU gives the factors, then the hand-off
+    t0 = time.time()
+    s.alm()
+    s.alm_to_admm()
+    res = s.results()
+    rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
+    be.init_constr(host.PAIR_UV)
+    be.cal_obj(host.PAIR_UV)
+    err1 = be.update_dimacs(host.PAIR_UV)
+    log("rank %d: phase 1 took %.2fs (%d inner its), rho=%.4g err1=%.3e n=%d r=%d" %
+        (rank, time.time() - t0, int(res["alm_inner"]), rho, err1, info["n"], info["rank"]))
+    state_file = "/tmp/lorads_bench_state_%d.bin" % os.getpid()
+    if rank == 0 and world == 1 and not a.no_cpu:
+        U, V = be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0)
+        with open(state_file, "wb") as f:
+            f.write(np.asfortranarray(U).tobytes(order="F"))
+            f.write(np.asfortranarray(V).tobytes(order="F"))
+            f.write(be.get_vec(host.VEC_LAMBDA).tobytes())
+        err1_start = err1
+
+    # ---- warm-up, then exactly K timed steps
+    err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup)
+    s.hip_profile(1, a.sample_every)
+    s.hip_sync()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    err1, cg_iters, pobj, dobj = admm_steps(be, host, rho, err1, a.steps)
+    s.hip_sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = s.hip_profile_read()
+    s.hip_profile(0, 1)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(cg_iters)], dtype=torch.float64, device=device)
+        dist.all_reduce(c)
+        cg_iters = int(c.item())
+    b_mv, b_cg = s.hip_algorithmic_bytes(0)
+    out = None
+    if rank == 0:
+        mv_ms = prof["sampled_ms"] / prof["sampled"] if prof["sampled"] else float("nan")
+        achieved = b_mv / (mv_ms * 1e-3) / 1e9 if prof["sampled"] else None
+        out = {
+            "metric": "ADMM iters/sec (+ inner CG-iters/sec), single-block n=20000 r=40",
+            "value": world * a.steps / elapsed,
+            "unit": "ADMM iters/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "cg_iters_per_s": cg_iters / elapsed,
+            "cg_iters_per_admm_iter": cg_iters / (world * a.steps),
+            "config": {"workload": "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
+                                   % (a.workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]),
+                       "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": world,
+                       "parallelism": "block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration" if world > 1 else "single GPU",
+                       "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (a.times_log_rank, rho)},
+            "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
+            "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x) (k_pairdots+k_cv_from_T+k_sval+k_spmm, or k_op_diag)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "algorithmic_bytes_per_launch": b_mv, "avg_launch_ms": mv_ms,
+                         "launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"]),
+                         "cg_iter_bytes": b_cg,
+                         "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
+                         "traffic": None},
+        }
+        if world == 1 and not a.no_cpu:
+            try:
+                cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)
+                cb["host_cores_total"] = os.cpu_count()
+                out["cpu_baseline"] = cb
+                out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
+            finally:
+                if os.path.exists(state_file):
+                    os.remove(state_file)
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 0, "kind": "reference",
+                                   "sample": "timed at N=1 only"}
+    s.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

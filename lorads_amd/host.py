@@ -286,6 +286,42 @@ class Session:
             raise RuntimeError("HIP backend unavailable (code %d): %s -- the product has no CPU fallback" % (rc, path))
         return self.attach(st)
 
+    # ---- measurement hooks of the HIP library (bench.py)
+    def _hip(self):
+        if getattr(self, "_hiplib", None) is None:
+            lib = C.CDLL(os.path.join(LIB_DIR, "liblorads_hip.so"))
+            lib.lorads_hip_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.lorads_hip_profile_read.argtypes = [C.c_void_p, _dp]
+            lib.lorads_hip_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+            lib.lorads_hip_sync.argtypes = [C.c_void_p]
+            self.lib.lrd_hip_backend_raw_ctx.restype = C.c_void_p
+            self.lib.lrd_hip_backend_raw_ctx.argtypes = [C.POINTER(BackendStruct)]
+            self._hiplib = lib
+            self._hipctx = C.c_void_p(self.lib.lrd_hip_backend_raw_ctx(self.lib.lrd_session_backend(self.h)))
+        return self._hiplib, self._hipctx
+
+    def hip_profile(self, enable, sample_every=8):
+        lib, ctx = self._hip()
+        _check(lib.lorads_hip_profile(ctx, int(enable), int(sample_every)), "profile")
+
+    def hip_profile_read(self):
+        lib, ctx = self._hip()
+        out = (C.c_double * 8)()
+        _check(lib.lorads_hip_profile_read(ctx, out), "profile_read")
+        keys = ["matvec_launches", "matvec_ms_est", "cg_iters", "cg_solves", "sampled", "sampled_ms", "spmm_sampled",
+                "spmm_sampled_ms"]
+        return dict(zip(keys, [out[i] for i in range(8)]))
+
+    def hip_algorithmic_bytes(self, blk=0):
+        lib, ctx = self._hip()
+        a, b = C.c_double(), C.c_double()
+        _check(lib.lorads_hip_algorithmic_bytes(ctx, blk, C.byref(a), C.byref(b)), "algorithmic_bytes")
+        return a.value, b.value
+
+    def hip_sync(self):
+        lib, ctx = self._hip()
+        _check(lib.lorads_hip_sync(ctx), "sync")
+
     def set_allreduce(self, fn):
         """fn(ptr:int, count:int, on_device:bool) -> sums in place over ranks."""
         def _cb(user, buf, count, on_device):

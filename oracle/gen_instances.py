@@ -1,250 +1,11 @@
 #!/usr/bin/env python3
-"""Synthetic SDPA (.dat-s) instance generators for the parity oracle and the bench.
-
-TEST INFRASTRUCTURE (oracle/): nothing under lorads_amd/ imports this module.
-
-The reference ships no inputs, so every parity/bench instance is generated
-here with a fixed seed and written in SDPA sparse format, the only format the reference reads
-(reference: src_semi/io/lorads_file_io.c:21-293).  Conventions of that reader which the
-generators rely on:
-
-  * matrix number 0 is F0 and is NEGATED on load (C = -F0, lorads_file_io.c:279-281), so the
-    solver minimises <-F0, X>;
-  * entries are given once, upper triangle (i <= j), 1-based;
-  * entries with |value| < 1e-12 are dropped (lorads_file_io.c:250).
-
-Instances: maxcut (cfg2 / cfg3a), theta (cfg1), randsparse (cfg3b),
-blockdiag maxcut (cfg4), matrix completion (cfg5), dense-C.
-Each generator returns a dict(m, blocks=[n_k], b, entries=[(mat, blk, i, j, val)]) with 1-based
-indices, and `write_sdpa` serialises it.
-"""
-import argparse
-import math
+"""Shim: the generators live in lorads_amd/instances.py (the bench needs them too)."""
+import os
 import sys
 
-import numpy as np
-
-
-def _rand_edges(n, n_edges, rng):
-    """n_edges distinct undirected edges (i<j) on n nodes, 0-based, deterministic for a seed."""
-    max_e = n * (n - 1) // 2
-    if n_edges > max_e:
-        raise ValueError("too many edges")
-    if n_edges > max_e // 3:
-        iu, ju = np.triu_indices(n, 1)
-        sel = rng.choice(max_e, size=n_edges, replace=False)
-        sel.sort()
-        return np.stack([iu[sel], ju[sel]], 1)
-    seen = set()
-    out = []
-    while len(out) < n_edges:
-        k = n_edges - len(out)
-        a = rng.integers(0, n, size=2 * k + 16)
-        b = rng.integers(0, n, size=2 * k + 16)
-        for x, y in zip(a.tolist(), b.tolist()):
-            if x == y:
-                continue
-            if x > y:
-                x, y = y, x
-            key = x * n + y
-            if key in seen:
-                continue
-            seen.add(key)
-            out.append((x, y))
-            if len(out) == n_edges:
-                break
-    e = np.array(out, dtype=np.int64)
-    order = np.lexsort((e[:, 1], e[:, 0]))
-    return e[order]
-
-
-def maxcut(n, n_edges, seed, weights=None):
-    """max <L/4, X> s.t. X_ii = 1.  F0 = L/4 (=> C = -L/4), F_i = e_i e_i^T, b = 1."""
-    rng = np.random.default_rng(seed)
-    edges = _rand_edges(n, n_edges, rng)
-    w = np.ones(len(edges)) if weights is None else weights(rng, len(edges))
-    deg = np.zeros(n)
-    np.add.at(deg, edges[:, 0], w)
-    np.add.at(deg, edges[:, 1], w)
-    ent = []
-    for i in range(n):
-        if deg[i] != 0.0:
-            ent.append((0, 1, i + 1, i + 1, deg[i] / 4.0))
-    for (i, j), wij in zip(edges.tolist(), w.tolist()):
-        ent.append((0, 1, i + 1, j + 1, -wij / 4.0))
-    for i in range(n):
-        ent.append((i + 1, 1, i + 1, i + 1, 1.0))
-    return dict(m=n, blocks=[n], b=np.ones(n), entries=ent)
-
-
-def theta(n, n_edges, seed):
-    """Lovasz theta: max <J, X> s.t. tr X = 1, X_ij = 0 on edges.  m = n_edges + 1."""
-    rng = np.random.default_rng(seed)
-    edges = _rand_edges(n, n_edges, rng)
-    ent = []
-    for i in range(n):
-        for j in range(i, n):
-            ent.append((0, 1, i + 1, j + 1, 1.0))
-    for i in range(n):
-        ent.append((1, 1, i + 1, i + 1, 1.0))
-    for k, (i, j) in enumerate(edges.tolist()):
-        ent.append((k + 2, 1, i + 1, j + 1, 1.0))
-    b = np.zeros(n_edges + 1)
-    b[0] = 1.0
-    return dict(m=n_edges + 1, blocks=[n], b=b, entries=ent)
-
-
-def randsparse(n, m, seed, c_edges=None, n_diag=2, n_off=8, r0=5, dense_c=False):
-    """cfg3b: m random sparse symmetric A_i with n_diag diagonal + n_off off-diagonal entries, values
-    N(0,1); b = A(R0 R0^T), R0 ~ N(0,1)/sqrt(n) (n x r0) so the problem is feasible.  The objective
-    is C = L/4 + I/4 (graph Laplacian of a random graph plus a multiple of the identity; positive
-    definite, so min <C,X> over X >= 0 is bounded -- with C = -L/4 as in max-cut and no diagonal
-    constraints the SDP is unbounded and the reference diverges), or a dense PD matrix."""
-    rng = np.random.default_rng(seed)
-    ent = []
-    if dense_c:
-        g = rng.standard_normal((n, n))
-        cm = g @ g.T / n + np.eye(n)
-        for i in range(n):
-            for j in range(i, n):
-                ent.append((0, 1, i + 1, j + 1, float(-cm[i, j])))
-    else:
-        ce = 6 * n if c_edges is None else c_edges
-        edges = _rand_edges(n, ce, rng)
-        deg = np.zeros(n)
-        np.add.at(deg, edges[:, 0], 1.0)
-        np.add.at(deg, edges[:, 1], 1.0)
-        for i in range(n):  # F0 = -C  (the reader negates it back)
-            ent.append((0, 1, i + 1, i + 1, -(deg[i] / 4.0 + 0.25)))
-        for i, j in edges.tolist():
-            ent.append((0, 1, i + 1, j + 1, 0.25))
-    R0 = np.random.default_rng(seed + 1).standard_normal((n, r0)) / math.sqrt(n)
-    b = np.zeros(m)
-    for k in range(m):
-        d = rng.choice(n, size=n_diag, replace=False)
-        seen = set()
-        offs = []
-        while len(offs) < n_off:
-            i, j = rng.integers(0, n, size=2).tolist()
-            if i == j:
-                continue
-            if i > j:
-                i, j = j, i
-            if (i, j) in seen:
-                continue
-            seen.add((i, j))
-            offs.append((i, j))
-        vals = rng.standard_normal(n_diag + n_off)
-        acc = 0.0
-        for t, i in enumerate(sorted(d.tolist())):
-            ent.append((k + 1, 1, i + 1, i + 1, float(vals[t])))
-            acc += vals[t] * float(R0[i] @ R0[i])
-        for t, (i, j) in enumerate(sorted(offs)):
-            v = float(vals[n_diag + t])
-            ent.append((k + 1, 1, i + 1, j + 1, v))
-            acc += 2.0 * v * float(R0[i] @ R0[j])
-        b[k] = acc
-    return dict(m=m, blocks=[n], b=b, entries=ent)
-
-
-def blockdiag_maxcut(nblk, n_k, edges_k, seed0):
-    """cfg4: nblk independent max-cut blocks, block-separable constraints, m = nblk * n_k."""
-    ent = []
-    for k in range(nblk):
-        sub = maxcut(n_k, edges_k, seed0 + k)
-        for mat, _, i, j, v in sub["entries"]:
-            if mat == 0:
-                ent.append((0, k + 1, i, j, v))
-            else:
-                ent.append((mat + k * n_k, k + 1, i, j, v))
-    ent.sort(key=lambda e: (e[0], e[1]))
-    return dict(m=nblk * n_k, blocks=[n_k] * nblk, b=np.ones(nblk * n_k), entries=ent)
-
-
-def coupled_blocks(nblk, n_k, m, seed, n_diag=2, n_off=4, r0=3, c_edges=None):
-    """Block-diagonal SDP whose constraints COUPLE the blocks: every A_i has entries in every
-    block (dense-cone branch per block; Gauss-Seidel != Jacobi)."""
-    rng = np.random.default_rng(seed)
-    ent = []
-    b = np.zeros(m)
-    for k in range(nblk):
-        sub = randsparse(n_k, m, seed + 17 * (k + 1), c_edges=c_edges, n_diag=n_diag, n_off=n_off, r0=r0)
-        for mat, _, i, j, v in sub["entries"]:
-            ent.append((mat, k + 1, i, j, v))
-        b += sub["b"]
-    ent.sort(key=lambda e: (e[0], e[1]))
-    return dict(m=m, blocks=[n_k] * nblk, b=b, entries=ent)
-
-
-def matcomp(n1, n2, n_obs, rank, seed):
-    """cfg5: matrix completion as an SDP on the (n1+n2) block; A_k = 1/2 (e_i e_j^T + e_j e_i^T)
-    picks W_ij of the off-diagonal block, C = I (trace minimisation => F0 = -I)."""
-    rng = np.random.default_rng(seed)
-    n = n1 + n2
-    L = rng.standard_normal((n1, rank))
-    Rm = rng.standard_normal((n2, rank))
-    seen = set()
-    obs = []
-    while len(obs) < n_obs:
-        k = n_obs - len(obs)
-        ii = rng.integers(0, n1, size=k + 16).tolist()
-        jj = rng.integers(0, n2, size=k + 16).tolist()
-        for i, j in zip(ii, jj):
-            if (i, j) in seen:
-                continue
-            seen.add((i, j))
-            obs.append((i, j))
-            if len(obs) == n_obs:
-                break
-    obs.sort()
-    ent = [(0, 1, i + 1, i + 1, -1.0) for i in range(n)]
-    b = np.zeros(n_obs)
-    for k, (i, j) in enumerate(obs):
-        ent.append((k + 1, 1, i + 1, n1 + j + 1, 0.5))
-        b[k] = float(L[i] @ Rm[j])
-    return dict(m=n_obs, blocks=[n], b=b, entries=ent)
-
-
-def write_sdpa(prob, path):
-    with open(path, "w") as f:
-        f.write("%d\n%d\n" % (prob["m"], len(prob["blocks"])))
-        f.write(" ".join(str(d) for d in prob["blocks"]) + "\n")
-        f.write(" ".join(repr(float(x)) for x in prob["b"]) + "\n")
-        for mat, blk, i, j, v in prob["entries"]:
-            f.write("%d %d %d %d %r\n" % (mat, blk, i, j, float(v)))
-
-
-# named instances used by tests/golden and the bench
-NAMED = {
-    # small parity instances (sizes chosen so the reference picks the intended branch)
-    "maxcut100": lambda: maxcut(100, 200, 101),            # sparse pattern branch, dense cone
-    "theta30": lambda: theta(30, 40, 1),                   # dense C => dense (dsyr2k/dsymm) branch
-    "theta50": lambda: theta(50, 103, 1),                  # cfg1 look-alike (m = 104)
-    "rand120": lambda: randsparse(120, 40, 2001, c_edges=150, n_diag=2, n_off=3, r0=3),
-    "blk4x60": lambda: blockdiag_maxcut(4, 60, 80, 4000),  # sparse-cone branch, separable
-    "coupled3x70": lambda: coupled_blocks(3, 70, 30, 3100, n_diag=1, n_off=2, r0=2, c_edges=60),
-    "densec40": lambda: randsparse(40, 20, 777, n_diag=1, n_off=2, r0=2, dense_c=True),
-    "matcomp60": lambda: matcomp(30, 30, 200, 3, 50),
-    # timing / log-level instances
-    "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
-    "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini
-    "rand4000": lambda: randsparse(4000, 1000, 20001, c_edges=24000),  # cfg3b-mini
-    # headline configs
-    "maxcut20000": lambda: maxcut(20000, 120000, 20000),   # cfg3a
-    "rand20000": lambda: randsparse(20000, 5000, 20001, c_edges=120000),  # cfg3b (headline bench)
-    "blk16x4000": lambda: blockdiag_maxcut(16, 4000, 24000, 4000),  # cfg4
-    "matcomp50000": lambda: matcomp(25000, 25000, 200000, 10, 50000),  # cfg5
-}
-
-
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("name", choices=sorted(NAMED))
-    ap.add_argument("out")
-    a = ap.parse_args(argv)
-    write_sdpa(NAMED[a.name](), a.out)
-    return 0
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lorads_amd.instances import *  # noqa: F401,F403,E402
+from lorads_amd.instances import NAMED, main, write_sdpa  # noqa: F401,E402
 
 if __name__ == "__main__":
     sys.exit(main())

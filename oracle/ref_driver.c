@@ -361,6 +361,9 @@ static int mode_admm_bench(ctx_t *c, lorads_params *p, int n_admm, const char *u
             if (fread(S->var->U[k]->matElem, 8, cnt, fp) != cnt) return 1;
             if (fread(S->var->V[k]->matElem, 8, cnt, fp) != cnt) return 1;
         }
+        /* optional: dual vector after the factors */
+        if (fread(S->var->dualVar, 8, (size_t)S->nRows, fp) != (size_t)S->nRows)
+            memset(S->var->dualVar, 0, sizeof(double) * (size_t)S->nRows);
         fclose(fp);
     }
     double rho = fixrho > 0 ? fixrho : c->admm.rho;
