@@ -70,12 +70,17 @@ def admm_steps(be, host, rho, err1, steps):
     """`steps` ADMM iterations through the operator table; returns (err1, cg_iters, pobj, dobj)."""
     cg = 0
     pobj = dobj = 0.0
+    fused = be.has_admm_step
     for _ in range(steps):
         tol = min(err1 * 1e-2, 1e-8)
-        cg += be.admm_update_var(rho, tol, 800)
-        pobj = be.cal_obj(host.PAIR_UV)
-        dobj = be.cal_dual_obj()
-        err1 = be.update_dimacs(host.PAIR_UV)
+        if fused:   # same four calls behind one C-ABI entry with a single host sync
+            c, pobj, dobj, err1 = be.admm_step(rho, tol, 800)
+            cg += c
+        else:
+            cg += be.admm_update_var(rho, tol, 800)
+            pobj = be.cal_obj(host.PAIR_UV)
+            dobj = be.cal_dual_obj()
+            err1 = be.update_dimacs(host.PAIR_UV)
         be.update_dual_var(rho)
     return err1, cg, pobj, dobj
 

@@ -97,6 +97,10 @@ int lorads_hip_cal_obj(lorads_hip_ctx *ctx, int32_t pair, double *pobj);
  * *cg_iters = sum of the CG iteration counts the reference would add to ASolver->cgIter */
 int lorads_hip_admm_update_var(lorads_hip_ctx *ctx, double rho, double cg_tol, int32_t cg_max_iter,
                                int32_t *cg_iters);
+/* One ADMM iteration up to (not including) the dual update, i.e. admmUpdateVar + calObj_admm +
+ * LORADSCalDualObj + updateDimacsADMM in the order of lorads_admm.c:76-81, with ONE host
+ * synchronisation: out = { cg iterations, <C,RR^T> (unscaled), b.lambda (unscaled), err1 } */
+int lorads_hip_admm_step(lorads_hip_ctx *ctx, double rho, double cg_tol, int32_t cg_max_iter, double out[4]);
 /* LORADSUpdateDualVar / LORADSCalDualObj (lorads_alg_common.c:319-340) */
 int lorads_hip_update_dual_var(lorads_hip_ctx *ctx, double rho);
 int lorads_hip_cal_dual_obj(lorads_hip_ctx *ctx, double *dobj);
@@ -114,7 +118,7 @@ int lorads_hip_get_vec(lorads_hip_ctx *ctx, int32_t which, double *v);
 int lorads_hip_set_allreduce(lorads_hip_ctx *ctx, lorads_hip_allreduce_fn fn, void *user);
 
 /* measurement hooks (bench.py): HIP-event timing of the dominant kernels on the library's stream.
- * stats[0..7] = {cg_matvec launches, cg_matvec total ms, cg iterations, cg solves,
+ * stats[0..7] = {cg_matvec launches, speculation misses (resumed solves), cg iterations, cg solves,
  *                sampled matvec launches, sampled matvec ms, spmm sampled launches, spmm sampled ms} */
 int lorads_hip_profile(lorads_hip_ctx *ctx, int32_t enable, int32_t sample_every);
 int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);

@@ -12,23 +12,31 @@
 //     operations run over sum_k n_k r_k in one launch.  The ABI movers transpose to/from the
 //     reference's column-major layout.
 //   * A_i: unique lower-triangular positions of all A_i of the cone ("A-pattern", PA entries) +
-//     CSR constraint -> (entry, value) + its transpose entry -> (constraint, value) + a full
+//     CSR constraint -> (entry, value) + its transpose entry -> (constraint, value) + the Gram
+//     matrix G = A A^T over pattern entries (S = G T in one pass, when it is small) + a full
 //     symmetric adjacency row -> (neighbour row, entry) for gather-form S*X (no atomics,
 //     bitwise reproducible).
-//   * C ∪ A "union pattern" (PU) with the same three structures, used by the RHS / gradient
-//     weighted-sum products (C + sum_i w_i A_i) X.
+//   * C u A "union pattern" (PU) with transpose + adjacency, used by the RHS / gradient weighted-sum
+//     products (C + sum_i w_i A_i) X.
 //
-// Kernels (all HBM/L2-bound integer+FP64 gather work; bytes per unit in DESIGN.md):
+// Kernels (HBM/L2-bound integer+FP64 gather work; bytes per unit in DESIGN.md):
 //   k_pairdots   T_e = X_p.Y_q + X_q.Y_p on a pattern            (reference LORADSUVt)
-//   k_cv_from_T  w_i = sum_k a_k T_e(k)                           (mul_inner_rk_double / coneAUV)
+//   k_cv         w_i = sum_k a_k T_e(k) (+ running-sum update)     (mul_inner_rk_double / coneAUV)
 //   k_sval       S_e = [C_e] + sum_(i,a) weight_i a               (sdpDataWSum / addObjCoeff)
+//   k_sgram      S = G T                                          (coneAUV + sdpDataWSum fused)
 //   k_spmm       Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm)
 //   k_op_diag    fused operator when every A_i = a e_p e_p^T (Max-Cut): one pass
-//   k_cg_*       CG vector updates with device-resident scalars (CGSolve)
-//   misc         averaging, scatter-add, dual update, line-search dots, L-BFGS axpy/dot
+//   k_cg_*       CG vector updates with device-resident scalars   (CGSolve)
+//   k_eval_final ||b - sum||^2, b.lambda in one workgroup
+//   misc         averaging, dual update, line-search dots, L-BFGS axpy/dot
+//
+// Launch structure: one ADMM iteration (2 CG solves per cone, constraint refreshes, objective,
+// DIMACS) is enqueued on one stream WITHOUT host round trips, using the iteration counts of the
+// previous ADMM iteration as a speculation and device-side gates (struct Guard); the host
+// synchronises once per ADMM iteration and resumes a solve that needed more iterations.
 //
 // Reductions: every reducing kernel writes one partial per workgroup; the consumer re-sums the
-// partials (<= 2048) in a fixed order, so results do not depend on scheduling.  Wave-level sums use
+// partials (<= 4096) in a fixed order, so results do not depend on scheduling.  Wave-level sums use
 // 64-lane __shfl_xor butterflies.
 #include <hip/hip_runtime.h>
 
@@ -46,6 +54,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int MAXPART = 4096; // capacity of one partial-sum slot
+constexpr int NSLOT = 10;
 
 thread_local std::string g_err;
 int fail(const char *what, hipError_t e) {
@@ -56,10 +65,10 @@ int fail_msg(const std::string &m) {
     g_err = m;
     return 1;
 }
-#define HC(call)                                          \
-    do {                                                  \
-        hipError_t e__ = (call);                          \
-        if (e__ != hipSuccess) return fail(#call, e__);   \
+#define HC(call)                                        \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) return fail(#call, e__); \
     } while (0)
 
 // ------------------------------------------------------------------ device helpers
@@ -96,77 +105,105 @@ struct CGState {
     int nan;
     int pad;
 };
+// Launch gating.  A whole ADMM iteration is enqueued without host round trips: kernels of a CG solve
+// exit at once when that solve is finished (`skip` -> its done word != 0), and everything that comes
+// after a solve (the next solve, the constraint refresh, the evaluation) exits at once when that solve
+// is NOT finished yet (`need` -> its done word == 0); the host then resumes from exactly that point.
+struct Guard {
+    const int *skip;
+    const int *need;
+};
+__device__ __forceinline__ bool blocked(const Guard &g) { return (g.skip && *g.skip != 0) || (g.need && *g.need == 0); }
 
 enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2 };
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
-enum { CHK_INIT = 0, CHK_ITER = 1, CHK_RESTART = 2 };
-enum { DIR_INIT = 0, DIR_BETA = 1, DIR_RESTART = 2 };
+enum { CHK_ITER = 1, CHK_RESTART = 2 };
+enum { DIR_BETA = 1, DIR_RESTART = 2 };
+enum { CV_SET = 0, CV_ADD = 1, CV_DELTA = 2 };
 
 // ------------------------------------------------------------------ kernels
+// pair dot of one pattern entry, LG lanes, 16-byte loads when r is even
+template <int LG, bool V2>
+__device__ __forceinline__ double pair_dot(const double *__restrict__ X, const double *__restrict__ Y, int p, int q, int r,
+                                           int lane) {
+    const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
+    double s = 0.0;
+    if (V2) {
+        const double2 *xp2 = (const double2 *)xp, *yq2 = (const double2 *)yq;
+        const int h = r >> 1;
+        if (p == q) {
+            for (int j = lane; j < h; j += LG) { const double2 a = xp2[j], b = yq2[j]; s += a.x * b.x + a.y * b.y; }
+        } else {
+            const double2 *xq2 = (const double2 *)(X + (size_t)q * r), *yp2 = (const double2 *)(Y + (size_t)p * r);
+            for (int j = lane; j < h; j += LG) {
+                const double2 a = xp2[j], b = yq2[j], c = xq2[j], d = yp2[j];
+                s += (a.x * b.x + a.y * b.y) + (c.x * d.x + c.y * d.y);
+            }
+        }
+    } else {
+        if (p == q) {
+            for (int j = lane; j < r; j += LG) s += xp[j] * yq[j];
+        } else {
+            const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
+            for (int j = lane; j < r; j += LG) s += xp[j] * yq[j] + xq[j] * yp[j];
+        }
+    }
+    return s;
+}
+
 // T_e = X_p.Y_q + X_q.Y_p  (p != q)   |   X_p.Y_p  (p == q); LG lanes share one pattern entry
-template <int LG>
+template <int LG, bool V2>
 __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
                                                   const double *__restrict__ X, const double *__restrict__ Y, int r,
-                                                  double *__restrict__ T, const CGState *st) {
-    if (st && st->done) return;
+                                                  double *__restrict__ T, Guard g) {
+    if (blocked(g)) return;
     const int e = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = e < ne;
     const int p = act ? erow[e] : 0, q = act ? ecol[e] : 0;
-    const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
-    double s = 0.0;
-    if (p == q) {
-        for (int j = lane; j < r; j += LG) s += xp[j] * yq[j];
-    } else {
-        const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
-        for (int j = lane; j < r; j += LG) s += xp[j] * yq[j] + xq[j] * yp[j];
-    }
+    double s = pair_dot<LG, V2>(X, Y, p, q, r, lane);
     s = group_sum<LG>(s);
     if (act && lane == 0) T[e] = s;
 }
 
 // partial of sum_e c_e * pairdot_e  (objective <C, sym(X Y^T)>); grid-stride so that the grid stays <= MAXPART
-template <int LG>
+template <int LG, bool V2>
 __global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
                                              const double *__restrict__ cval, const double *__restrict__ X,
-                                             const double *__restrict__ Y, int r, double *__restrict__ part) {
+                                             const double *__restrict__ Y, int r, double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
+    if (blocked(g)) return;
     const int lane = threadIdx.x % LG, per = TPB / LG;
     double s = 0.0; // every lane keeps its own slice; the block sum adds the slices
-    for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per) {
-        const int p = erow[e], q = ecol[e];
-        const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
-        double d = 0.0;
-        if (p == q) {
-            for (int j = lane; j < r; j += LG) d += xp[j] * yq[j];
-        } else {
-            const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
-            for (int j = lane; j < r; j += LG) d += xp[j] * yq[j] + xq[j] * yp[j];
-        }
-        s += d * cval[e];
-    }
+    for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per)
+        s += pair_dot<LG, V2>(X, Y, erow[e], ecol[e], r, lane) * cval[e];
     const double t = block_sum(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// w_i = scale * sum_k a_k T[e_k]; 8 lanes per constraint
-__global__ __launch_bounds__(TPB) void k_cv_from_T(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
-                                                   const double *__restrict__ a_val, const double *__restrict__ T,
-                                                   double scale, double *__restrict__ cv, const CGState *st) {
-    if (st && st->done) return;
+// w_i = sum_k a_k T[e_k]; 8 lanes per constraint.  `mode` says what happens to the running
+// m-vector `vec` (constrValSum / q1 / q2): CV_SET vec[g] = scale w, CV_ADD vec[g] += scale w,
+// CV_DELTA vec[g] += w - old (the subtract/recompute/add bookkeeping of LORADSUpdateSDPVar,
+// lorads_alg_common.c:199-203); cv (compact constrVal[k]) gets w
+__global__ __launch_bounds__(TPB) void k_cv(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
+                                            const double *__restrict__ a_val, const double *__restrict__ T, double scale,
+                                            double *__restrict__ cv, int mode, const int *__restrict__ row_idx,
+                                            double *__restrict__ vec, Guard g) {
+    if (blocked(g)) return;
     const int i = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
     const bool act = i < nrow;
     double s = 0.0;
     if (act)
         for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) s += a_val[t] * T[a_e[t]];
     s = group_sum<8>(s);
-    if (act && lane == 0) cv[i] = s * scale;
-}
-
-// vec[row_idx[i]] += alpha * cv[i]  (row_idx unique within one cone)
-__global__ void k_scatter_add(int nrow, const int *__restrict__ row_idx, const double *__restrict__ cv, double alpha,
-                              double *__restrict__ vec) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nrow) vec[row_idx[i]] += alpha * cv[i];
+    if (act && lane == 0) {
+        if (vec) {
+            const int gi = row_idx[i];
+            if (mode == CV_SET) vec[gi] = s * scale;
+            else if (mode == CV_ADD) vec[gi] += s * scale;
+            else vec[gi] += s - cv[i];
+        }
+        if (cv) cv[i] = s;
+    }
 }
 
 struct WArgs {
@@ -187,29 +224,44 @@ __device__ __forceinline__ double weight_of(int mode, const WArgs &a, int i) {
 // S_e = [cbase_e] + sum over the constraints touching e of weight_i * a
 __global__ __launch_bounds__(TPB) void k_sval(int ne, const int *__restrict__ e_ptr, const int *__restrict__ e_con,
                                               const double *__restrict__ e_val, const double *__restrict__ cbase, int mode,
-                                              WArgs wa, double *__restrict__ S, const CGState *st) {
-    if (st && st->done) return;
+                                              WArgs wa, double *__restrict__ S, Guard g) {
+    if (blocked(g)) return;
     const int e = blockIdx.x * TPB + threadIdx.x;
     if (e >= ne) return;
     double s = cbase ? cbase[e] : 0.0;
     for (int t = e_ptr[e]; t < e_ptr[e + 1]; ++t) s += weight_of(mode, wa, e_con[t]) * e_val[t];
     S[e] = s;
 }
+// S = G T with G = A A^T over pattern entries (w = A T and S = A^T w in one pass)
+__global__ __launch_bounds__(TPB) void k_sgram(int ne, const int *__restrict__ g_ptr, const int *__restrict__ g_col,
+                                               const double *__restrict__ g_val, const double *__restrict__ T,
+                                               double *__restrict__ S, Guard g) {
+    if (blocked(g)) return;
+    const int e = blockIdx.x * TPB + threadIdx.x;
+    if (e >= ne) return;
+    double s = 0.0;
+    for (int t = g_ptr[e]; t < g_ptr[e + 1]; ++t) s += g_val[t] * T[g_col[t]];
+    S[e] = s;
+}
 
-// Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction
-template <int LG>
+// Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction.
+// V2: every lane owns column pairs (16-byte loads), r even.
+template <int LG, bool V2>
 __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj_ptr, const int *__restrict__ adj_col,
                                               const int *__restrict__ adj_e, const double *__restrict__ S,
                                               const double *__restrict__ X, int r, int mode, const double *__restrict__ xin,
                                               const double *__restrict__ rhs, double rho, double *__restrict__ out,
-                                              double *__restrict__ part, const CGState *st) {
+                                              double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
-    if (st && st->done) return;
+    if (blocked(g)) return;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
-    double acc[8];
+    constexpr int W = V2 ? 2 : 1;   // columns per lane per step
+    double acc[8][W];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
     if (act) {
         const int t1 = adj_ptr[row + 1];
         for (int t = adj_ptr[row]; t < t1; ++t) {
@@ -217,8 +269,11 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
             const double *xq = X + (size_t)adj_col[t] * r;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const int j = lane + c * LG;
-                if (j < r) acc[c] += s * xq[j];
+                const int j = (lane + c * LG) * W;
+                if (j < r) {
+                    if (V2) { const double2 v = *(const double2 *)(xq + j); acc[c][0] += s * v.x; acc[c][W - 1] += s * v.y; }
+                    else acc[c][0] += s * xq[j];
+                }
             }
         }
     }
@@ -226,15 +281,20 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
     if (act) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const int j = lane + c * LG;
-            if (j < r) {
-                const size_t idx = (size_t)row * r + j;
-                double v;
-                if (mode == OP_CG) { const double xi = xin[idx]; v = xi + acc[c]; local += xi * v; }
-                else if (mode == OP_RES) { v = rhs[idx] - (xin[idx] + acc[c]); local += v * v; }
-                else if (mode == OP_RHS) { v = X[idx] - acc[c] / rho; local += fabs(v); }
-                else { v = 2.0 * acc[c]; local += v * v; }
-                out[idx] = v;
+            const int j0 = (lane + c * LG) * W;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int j = j0 + w;
+                if (j < r) {
+                    const size_t idx = (size_t)row * r + j;
+                    const double a = acc[c][w];
+                    double v;
+                    if (mode == OP_CG) { const double xi = xin[idx]; v = xi + a; local += xi * v; }
+                    else if (mode == OP_RES) { v = rhs[idx] - (xin[idx] + a); local += v * v; }
+                    else if (mode == OP_RHS) { v = X[idx] - a / rho; local += fabs(v); }
+                    else { v = 2.0 * a; local += v * v; }
+                    out[idx] = v;
+                }
             }
         }
     }
@@ -245,11 +305,11 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
 // Max-Cut-type cones (every A_i = a_i e_p e_p^T): the whole operator is row-local,
 //   out_p = x_p + g_p (x_p . V_p) V_p,  g_p = sum_i a_i^2  -> one pass over x and V
 template <int LG>
-__global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict__ g, const double *__restrict__ V, int r,
+__global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict__ gd, const double *__restrict__ V, int r,
                                                  int mode, const double *__restrict__ xin, const double *__restrict__ rhs,
-                                                 double *__restrict__ out, double *__restrict__ part, const CGState *st) {
+                                                 double *__restrict__ out, double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
-    if (st && st->done) return;
+    if (blocked(g)) return;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
     double xv[8], vv[8], d = 0.0;
@@ -261,7 +321,7 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
         vv[c] = ok ? V[(size_t)row * r + j] : 0.0;
         d += xv[c] * vv[c];
     }
-    d = group_sum<LG>(d) * (act ? g[row] : 0.0);
+    d = group_sum<LG>(d) * (act ? gd[row] : 0.0);
     double local = 0.0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -278,13 +338,31 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// start of CGSolve (lorads_cgs.c:115,149-172): ||b||_1 and the initial residual norm from partials; every
+// workgroup recomputes the two sums (same order -> same value), workgroup 0 publishes the state; p = r
+__global__ __launch_bounds__(TPB) void k_cg_init(size_t len, CGState *st, const double *__restrict__ part_rr, int nrr,
+                                                 const double *__restrict__ part_b, int nb, double tol,
+                                                 const double *__restrict__ r, double *__restrict__ p, Guard g) {
+    __shared__ double sh[4];
+    if (blocked(g)) return;
+    const double a = sum_partials(part_rr, nrr, sh);
+    const double b = sum_partials(part_b, nb, sh);
+    const bool conv = sqrt(a) / b < tol;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rr = a; st->bnorm = b; st->beta = 0.0; st->iter = 0; st->nan = 0; st->pad = 0;
+        st->done = conv ? 2 : 0;
+    }
+    if (conv) return;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) p[i] = r[i];
+}
+
 // x += alpha p, r -= alpha Q, partial ||r||^2; alpha = rr / (p.Q) from device scalars (lorads_cgs.c:181-189)
 __global__ __launch_bounds__(TPB) void k_cg_update(size_t len, const CGState *st, const double *__restrict__ part_pq, int npq,
                                                    double *__restrict__ x, double *__restrict__ r,
                                                    const double *__restrict__ p, const double *__restrict__ Q,
-                                                   double *__restrict__ part_rr) {
+                                                   double *__restrict__ part_rr, Guard g) {
     __shared__ double sh[4];
-    if (st->done) return;
+    if (blocked(g)) return;
     const double pq = sum_partials(part_pq, npq, sh);
     const double alpha = st->rr / pq;
     double local = 0.0;
@@ -299,47 +377,43 @@ __global__ __launch_bounds__(TPB) void k_cg_update(size_t len, const CGState *st
 }
 
 // scalar bookkeeping of CGSolve, one workgroup
-__global__ __launch_bounds__(TPB) void k_cg_check(CGState *st, int kind, const double *__restrict__ part_a, int na,
-                                                  const double *__restrict__ part_b, int nb, double tol, int maxiter) {
+__global__ __launch_bounds__(TPB) void k_cg_check(CGState *st, int kind, const double *__restrict__ part_a, int na, double tol,
+                                                  int maxiter, Guard g) {
     __shared__ double sh[4];
-    if (kind != CHK_INIT && st->done) return;
+    if (blocked(g)) return;
     const double a = sum_partials(part_a, na, sh);
-    double b = 0.0;
-    if (kind == CHK_INIT) b = sum_partials(part_b, nb, sh);
     if (threadIdx.x != 0) return;
-    if (kind == CHK_INIT) { // lorads_cgs.c:115,149-160
-        st->rr = a;
-        st->bnorm = b;
-        st->beta = 0.0;
-        st->nan = 0;
-        if (sqrt(a) / b < tol) st->done = 2;
-        else { st->done = 0; st->iter = 0; }
-    } else if (kind == CHK_ITER) { // :189-194, :217-224
+    if (kind == CHK_ITER) { // lorads_cgs.c:189-194, :217-224
         st->iter += 1;
         if (a != a) st->nan = 1;
-        if (sqrt(a) / st->bnorm < tol) st->done = 1;
-        else if (st->iter >= maxiter) st->done = 3;
         st->beta = a / st->rr;
         st->rr = a;
+        if (sqrt(a) / st->bnorm < tol) st->done = 1;
+        else if (st->iter >= maxiter) st->done = 3;
     } else { // restart: true residual, then beta = qTrNew/qTr = 1 (:195-221)
         st->rr = a;
         st->beta = 1.0;
     }
 }
 
-__global__ void k_cg_dir(size_t len, const CGState *st, int kind, const double *__restrict__ r, double *__restrict__ p) {
-    if (st->done) return;
+__global__ void k_cg_dir(size_t len, const CGState *st, int kind, const double *__restrict__ r, double *__restrict__ p, Guard g) {
+    if (blocked(g)) return;
     const double beta = st->beta;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
         const double rv = r[i];
-        p[i] = kind == DIR_INIT ? rv : (kind == DIR_RESTART ? rv + rv : rv + beta * p[i]);
+        p[i] = kind == DIR_RESTART ? rv + rv : rv + beta * p[i];
     }
 }
 
 // ---- small vector kernels
-__global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out) {
+__global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out, Guard g) {
+    if (blocked(g)) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
         out[i] = (u[i] + v[i]) / 2;
+}
+__global__ void k_zero(size_t len, double *__restrict__ y, Guard g) {
+    if (blocked(g)) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) y[i] = 0.0;
 }
 __global__ void k_axpy(size_t len, double a, const double *__restrict__ x, double *__restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
@@ -379,29 +453,35 @@ __global__ __launch_bounds__(TPB) void k_dot(size_t len, const double *__restric
     const double t = block_sum(local, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ part, int n, double *out) {
+// out (= or +=) scale * sum(part)
+__global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ part, int n, double scale, int accumulate,
+                                                  double *out, Guard g) {
     __shared__ double sh[4];
+    if (blocked(g)) return;
     const double t = sum_partials(part, n, sh);
-    if (threadIdx.x == 0) *out = t;
+    if (threadIdx.x == 0) *out = accumulate ? *out + scale * t : scale * t;
 }
 enum { SOP_ALPHA = 0, SOP_W = 1, SOP_BETA = 2 };
-// scalar algebra of the two-loop recursion: sc = {dot, coef}; ring scalars in (alpha, beta)
+// scalar algebra of the two-loop recursion
 __global__ void k_scalar_op(int op, const double *dot, double *alpha, double *beta, double *coef) {
     if (op == SOP_ALPHA) { *alpha = *beta * *dot; *coef = -1 * *alpha; }
     else if (op == SOP_W) { *coef = *alpha - *beta * *dot; }
     else { *beta = 1.0 / *dot; }
 }
-// err^2 partial of b - csum
-__global__ __launch_bounds__(TPB) void k_vio(int m, const double *__restrict__ b, const double *__restrict__ csum,
-                                             double *__restrict__ part) {
+// one workgroup: out[0] = sum (b-csum)^2, out[1] = b.lambda   (primalInfeasibility, LORADSCalDualObj)
+__global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restrict__ b, const double *__restrict__ csum,
+                                                    const double *__restrict__ lambda, double *out, Guard g) {
     __shared__ double sh[4];
-    double local = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
-        const double d = b[i] - csum[i];
-        local += d * d;
+    if (blocked(g)) return;
+    double v = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < m; i += TPB) {
+        const double t = b[i] - csum[i];
+        v += t * t;
+        d += b[i] * lambda[i];
     }
-    const double t = block_sum(local, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    v = block_sum(v, sh);
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) { out[0] = v; out[1] = d; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -415,21 +495,21 @@ __global__ void k_csum_step(int m, double tau, const double *__restrict__ q1, co
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) { double c = csum[i] + tau * q1[i]; csum[i] = c + (tau * tau) * q2[i]; }
 }
-// five dots of the line search in one pass (single workgroup grid-stride; m is small)
+// five dots of the line search in one workgroup -> out[0..4]
 __global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const double *__restrict__ b,
                                                     const double *__restrict__ csum, const double *__restrict__ lambda,
                                                     const double *__restrict__ q1, const double *__restrict__ q2,
-                                                    double *__restrict__ part /* 5 x gridDim */) {
+                                                    double *__restrict__ out) {
     __shared__ double sh[4];
     double s[5] = {0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+    for (int i = threadIdx.x; i < m; i += TPB) {
         const double q0 = (b[i] - csum[i]) + rinv * lambda[i];
         const double a1 = q1[i], a2 = q2[i];
         s[0] += a2 * a2; s[1] += a1 * a2; s[2] += a1 * a1; s[3] += q0 * a2; s[4] += q0 * a1;
     }
     for (int k = 0; k < 5; ++k) {
         const double t = block_sum(s[k], sh);
-        if (threadIdx.x == 0) part[k * gridDim.x + blockIdx.x] = t;
+        if (threadIdx.x == 0) out[k] = t;
     }
 }
 
@@ -468,16 +548,18 @@ struct Block {
     int *a_ptr = nullptr, *a_e = nullptr;  // constraint CSR over the A-pattern
     double *a_val = nullptr;
     Pattern pa, pu;
+    bool has_gram = false;    // G = A A^T over A-pattern entries
+    int *g_ptr = nullptr, *g_col = nullptr;
+    double *g_val = nullptr;
     double *T = nullptr;      // pair dots on the A-pattern
     double *cv = nullptr;     // constrVal[k], compact
     double *wtmp = nullptr;   // compact weights inside the CG operator
     int *c_row = nullptr, *c_col = nullptr;
     double *c_val = nullptr;
-    std::vector<int> h_c_pu;  // position of each C entry in the union pattern (host)
-    std::vector<double> h_c_val;
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
+    int spec[2] = {1, 1};     // speculated CG iterations of the U- and V-solve
     double bytes_mv = 0, bytes_cg = 0;
 };
 
@@ -497,9 +579,11 @@ struct lorads_hip_ctx {
     double *cr = nullptr, *cp = nullptr, *cQ = nullptr, *rhs = nullptr; // flat CG vectors
     double *Dtmp = nullptr;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
-    double *part = nullptr;   // 8 x MAXPART partial sums
+    double *part = nullptr;   // NSLOT x MAXPART partial sums
     double *scal = nullptr;   // 64 device scalars
-    CGState *st = nullptr;
+    CGState *st = nullptr;    // one per (cone, half)
+    CGState *h_st = nullptr;  // pinned mirror
+    double *h_scal = nullptr; // pinned mirror of scalars
     std::vector<Ring> ring;
     double *ring_ab = nullptr; // [2L] alpha,beta per node
     int head = 0;
@@ -507,9 +591,8 @@ struct lorads_hip_ctx {
     void *ar_user = nullptr;
     // profiling
     int prof = 0, prof_every = 8;
-    long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0;
+    long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
     double ms_samp = 0, ms_samp_spmm = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_mv, pend_sp;
 };
 
@@ -518,14 +601,16 @@ namespace {
 inline int nblocks_for(size_t items, int per_block) { return (int)((items + per_block - 1) / per_block); }
 inline int grid1d(size_t len) {
     size_t g = (len + TPB - 1) / TPB;
-    return (int)std::min<size_t>(std::max<size_t>(g, 1), MAXPART);
+    return (int)std::min<size_t>(std::max<size_t>(g, 1), 2048);
 }
-inline int lg_for(int r) { return r <= 64 ? 8 : (r <= 256 ? 32 : 64); }
-inline int spmm_rows_per_block(int r) { return TPB / lg_for(r); }
+// lanes per row/entry: 16-byte loads (2 columns per lane) when r is even and fits 8 lanes x 8 steps x 2
+inline bool use_v2(int r) { return (r % 2) == 0 && r <= 128; }
+inline int lg_for(int r) { return use_v2(r) ? 8 : (r <= 64 ? 8 : (r <= 256 ? 32 : 64)); }
+const Guard NOGUARD{nullptr, nullptr};
 
 double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * MAXPART; }
 
-// ---- pattern construction (host, once per context / rank change is independent of it)
+// ---- pattern construction (host, once per context)
 struct HostPattern {
     std::vector<int> erow, ecol;
     std::vector<int> e_ptr, e_con;
@@ -533,7 +618,6 @@ struct HostPattern {
     std::vector<int> adj_ptr, adj_col, adj_e;
 };
 
-// positions: list of (row,col) lower-tri; returns unique sorted list and index of each input position
 void unique_positions(const std::vector<std::pair<int, int>> &pos, std::vector<std::pair<int, int>> &uniq,
                       std::vector<int> &index) {
     std::vector<int> order(pos.size());
@@ -611,10 +695,38 @@ int upload_pattern(Pattern &P, const HostPattern &hp, const std::vector<double> 
     return 0;
 }
 
+// G = A A^T over pattern entries, when sum_i nnz_i^2 stays small
+int build_gram(Block &B, const lorads_hip_block &hb, const std::vector<int> &a_e, int ne) {
+    double tot = 0;
+    for (int i = 0; i < hb.nrow; ++i) { double k = hb.a_ptr[i + 1] - hb.a_ptr[i]; tot += k * k; }
+    if (tot > std::max(64.0 * B.na, 1.0e6) || tot > 2.0e8) return 0;
+    std::vector<std::pair<uint64_t, double>> tri;
+    tri.reserve((size_t)tot);
+    for (int i = 0; i < hb.nrow; ++i)
+        for (int t1 = hb.a_ptr[i]; t1 < hb.a_ptr[i + 1]; ++t1)
+            for (int t2 = hb.a_ptr[i]; t2 < hb.a_ptr[i + 1]; ++t2)
+                tri.push_back({((uint64_t)a_e[t1] << 32) | (uint32_t)a_e[t2], hb.a_val[t1] * hb.a_val[t2]});
+    std::stable_sort(tri.begin(), tri.end(), [](const std::pair<uint64_t, double> &x, const std::pair<uint64_t, double> &y) {
+        return x.first < y.first;
+    });
+    std::vector<int> g_ptr(ne + 1, 0), g_col;
+    std::vector<double> g_val;
+    for (size_t k = 0; k < tri.size(); ++k) {
+        if (k > 0 && tri[k].first == tri[k - 1].first) { g_val.back() += tri[k].second; continue; }
+        g_col.push_back((int)(tri[k].first & 0xffffffffu));
+        g_val.push_back(tri[k].second);
+        g_ptr[(int)(tri[k].first >> 32) + 1]++;
+    }
+    for (int e = 0; e < ne; ++e) g_ptr[e + 1] += g_ptr[e];
+    if (upload(&B.g_ptr, g_ptr) || upload(&B.g_col, g_col) || upload(&B.g_val, g_val)) return 1;
+    B.has_gram = true;
+    return 0;
+}
+
 int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     B.n = hb.n; B.r = hb.rank; B.nrow = hb.nrow; B.na = hb.a_ptr[hb.nrow]; B.nc = hb.c_nnz;
     if (B.r > 512) return fail_msg("rank > 512 is not supported by the row kernels");
-    if (nblocks_for((size_t)B.n, spmm_rows_per_block(B.r)) > MAXPART) return fail_msg("cone dimension too large for the partial-sum slots of this build");
+    if (nblocks_for((size_t)B.n, 4) > MAXPART) return fail_msg("cone dimension too large for the partial-sum slots of this build");
     std::vector<std::pair<int, int>> posA(B.na), posU;
     for (int t = 0; t < B.na; ++t) {
         if (hb.a_row[t] < hb.a_col[t] || hb.a_col[t] < 0 || hb.a_row[t] >= hb.n) return fail_msg("A entry out of range / not lower-triangular");
@@ -632,7 +744,7 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     build_adjacency(B.n, uniqA, hpA);
     build_transpose((int)uniqA.size(), hb.nrow, hb.a_ptr, a_e, hb.a_val, hpA);
     if (upload_pattern(B.pa, hpA, nullptr)) return 1;
-    // union pattern C ∪ A
+    // union pattern C u A
     posU = posA;
     for (int t = 0; t < B.nc; ++t) posU.push_back({hb.c_row[t], hb.c_col[t]});
     std::vector<std::pair<int, int>> uniqU;
@@ -643,30 +755,29 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     std::vector<int> a_eU(u_idx.begin(), u_idx.begin() + B.na);
     build_transpose((int)uniqU.size(), hb.nrow, hb.a_ptr, a_eU, hb.a_val, hpU);
     std::vector<double> cbase(uniqU.size(), 0.0);
-    B.h_c_pu.assign(u_idx.begin() + B.na, u_idx.end());
-    B.h_c_val.assign(hb.c_val, hb.c_val + B.nc);
-    for (int t = 0; t < B.nc; ++t) cbase[B.h_c_pu[t]] += hb.c_val[t];
+    for (int t = 0; t < B.nc; ++t) cbase[u_idx[B.na + t]] += hb.c_val[t];
     if (upload_pattern(B.pu, hpU, &cbase)) return 1;
     // constraint CSR + misc
     std::vector<int> v_rowidx(hb.row_idx, hb.row_idx + hb.nrow), v_aptr(hb.a_ptr, hb.a_ptr + hb.nrow + 1);
-    std::vector<double> v_aval(hb.a_val, hb.a_val + B.na);
+    std::vector<double> v_aval(hb.a_val, hb.a_val + B.na), v_cval(hb.c_val, hb.c_val + B.nc);
     std::vector<int> v_crow(hb.c_row, hb.c_row + B.nc), v_ccol(hb.c_col, hb.c_col + B.nc);
     if (upload(&B.row_idx, v_rowidx) || upload(&B.a_ptr, v_aptr) || upload(&B.a_e, a_e) || upload(&B.a_val, v_aval) ||
-        upload(&B.c_row, v_crow) || upload(&B.c_col, v_ccol) || upload(&B.c_val, B.h_c_val))
+        upload(&B.c_row, v_crow) || upload(&B.c_col, v_ccol) || upload(&B.c_val, v_cval))
         return 1;
     if (dalloc(&B.T, (size_t)B.pa.ne) || dalloc(&B.cv, (size_t)B.nrow) || dalloc(&B.wtmp, (size_t)B.nrow)) return 1;
     HC(hipMemset(B.cv, 0, sizeof(double) * (size_t)std::max(B.nrow, 1)));
     // Max-Cut fast path
     bool diag = B.nrow > 0;
-    std::vector<double> g(B.n, 0.0);
+    std::vector<double> gd(B.n, 0.0);
     for (int i = 0; i < hb.nrow && diag; ++i) {
         if (hb.a_ptr[i + 1] - hb.a_ptr[i] != 1) { diag = false; break; }
         int t = hb.a_ptr[i];
         if (hb.a_row[t] != hb.a_col[t]) { diag = false; break; }
-        g[hb.a_row[t]] += hb.a_val[t] * hb.a_val[t];
+        gd[hb.a_row[t]] += hb.a_val[t] * hb.a_val[t];
     }
     B.diag_only = diag;
-    if (diag && upload(&B.gdiag, g)) return 1;
+    if (diag && upload(&B.gdiag, gd)) return 1;
+    if (!diag && build_gram(B, hb, a_e, B.pa.ne)) return 1;
     return 0;
 }
 
@@ -728,100 +839,84 @@ int allreduce_dev(lorads_hip_ctx *c, double *buf, int count) {
 }
 
 // ---- launch helpers
-template <int LG>
-void launch_pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, const CGState *st) {
+#define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, c->stream, __VA_ARGS__)
+
+void pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, Guard g) {
     if (P.ne == 0) return;
-    hipLaunchKernelGGL(k_pairdots<LG>, dim3(nblocks_for((size_t)P.ne, TPB / LG)), dim3(TPB), 0, c->stream, P.ne, P.erow, P.ecol, X,
-                       Y, r, T, st);
-}
-void pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, const CGState *st) {
-    switch (lg_for(r)) {
-    case 8: launch_pairdots<8>(c, P, X, Y, r, T, st); break;
-    case 32: launch_pairdots<32>(c, P, X, Y, r, T, st); break;
-    default: launch_pairdots<64>(c, P, X, Y, r, T, st); break;
-    }
+    const int lg = lg_for(r), grid = nblocks_for((size_t)P.ne, TPB / lg);
+    if (use_v2(r)) LAUNCH((k_pairdots<8, true>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
+    else if (lg == 8) LAUNCH((k_pairdots<8, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
+    else if (lg == 32) LAUNCH((k_pairdots<32, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
+    else LAUNCH((k_pairdots<64, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
 }
 // returns the number of partials written
-template <int LG>
-int launch_spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin,
-                const double *rhs, double rho, double *out, double *part, const CGState *st) {
-    int g = nblocks_for((size_t)B.n, TPB / LG);
-    hipLaunchKernelGGL(k_spmm<LG>, dim3(g), dim3(TPB), 0, c->stream, B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin,
-                       rhs, rho, out, part, st);
-    return g;
-}
 int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin, const double *rhs,
-         double rho, double *out, double *part, const CGState *st) {
-    switch (lg_for(B.r)) {
-    case 8: return launch_spmm<8>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
-    case 32: return launch_spmm<32>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
-    default: return launch_spmm<64>(c, B, P, X, mode, xin, rhs, rho, out, part, st);
-    }
+         double rho, double *out, double *part, Guard g) {
+    const int lg = lg_for(B.r), grid = nblocks_for((size_t)B.n, TPB / lg);
+#define SPMM_ARGS B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin, rhs, rho, out, part, g
+    if (use_v2(B.r)) LAUNCH((k_spmm<8, true>), grid, SPMM_ARGS);
+    else if (lg == 8) LAUNCH((k_spmm<8, false>), grid, SPMM_ARGS);
+    else if (lg == 32) LAUNCH((k_spmm<32, false>), grid, SPMM_ARGS);
+    else LAUNCH((k_spmm<64, false>), grid, SPMM_ARGS);
+#undef SPMM_ARGS
+    return grid;
 }
-template <int LG>
-int launch_op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs,
-                   double *out, double *part, const CGState *st) {
-    int g = nblocks_for((size_t)B.n, TPB / LG);
-    hipLaunchKernelGGL(k_op_diag<LG>, dim3(g), dim3(TPB), 0, c->stream, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, st);
-    return g;
+int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs, double *out,
+            double *part, Guard g) {
+    const int lg = B.r <= 64 ? 8 : (B.r <= 256 ? 32 : 64), grid = nblocks_for((size_t)B.n, TPB / lg);
+    if (lg == 8) LAUNCH(k_op_diag<8>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
+    else if (lg == 32) LAUNCH(k_op_diag<32>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
+    else LAUNCH(k_op_diag<64>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
+    return grid;
 }
-template <int LG>
-int launch_obj(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part) {
-    int g = std::min(nblocks_for((size_t)B.nc, TPB / LG), MAXPART);
-    hipLaunchKernelGGL(k_obj<LG>, dim3(g), dim3(TPB), 0, c->stream, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part);
-    return g;
-}
-int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part) {
+int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part, Guard g) {
     if (B.nc == 0) return 0;
-    switch (lg_for(B.r)) {
-    case 8: return launch_obj<8>(c, B, X, Y, part);
-    case 32: return launch_obj<32>(c, B, X, Y, part);
-    default: return launch_obj<64>(c, B, X, Y, part);
-    }
+    const int lg = lg_for(B.r), grid = std::min(nblocks_for((size_t)B.nc, TPB / lg), 1024);
+    if (use_v2(B.r)) LAUNCH((k_obj<8, true>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
+    else if (lg == 8) LAUNCH((k_obj<8, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
+    else if (lg == 32) LAUNCH((k_obj<32, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
+    else LAUNCH((k_obj<64, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
+    return grid;
 }
 
-// cv = scale * A_k(sym(X Y^T))   (LORADSInitConstrVal, lorads_alg_common.c:71-76)
-void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, double scale, double *cv, const CGState *st) {
+// cv = A_k(sym(X Y^T))   (LORADSInitConstrVal, lorads_alg_common.c:71-76) and, per `mode`, the running m-vector
+void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, double scale, double *cv, int mode, double *vec,
+                Guard g) {
     if (B.nrow == 0) return;
-    pairdots(c, B.pa, X, Y, B.r, B.T, st);
-    hipLaunchKernelGGL(k_cv_from_T, dim3(nblocks_for((size_t)B.nrow, TPB / 8)), dim3(TPB), 0, c->stream, B.nrow, B.a_ptr, B.a_e,
-                       B.a_val, B.T, scale, cv, st);
+    pairdots(c, B.pa, X, Y, B.r, B.T, g);
+    LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T, scale, cv, mode, B.row_idx, vec, g);
 }
-void scatter_add(lorads_hip_ctx *c, const Block &B, const double *cv, double alpha, double *vec) {
-    if (B.nrow == 0) return;
-    hipLaunchKernelGGL(k_scatter_add, dim3(nblocks_for((size_t)B.nrow, TPB)), dim3(TPB), 0, c->stream, B.nrow, B.row_idx, cv, alpha,
-                       vec);
-}
-void sval(lorads_hip_ctx *c, const Block &B, const Pattern &P, bool with_c, int mode, const WArgs &wa, const CGState *st) {
+void sval(lorads_hip_ctx *c, const Pattern &P, bool with_c, int mode, const WArgs &wa, Guard g) {
     if (P.ne == 0) return;
-    hipLaunchKernelGGL(k_sval, dim3(nblocks_for((size_t)P.ne, TPB)), dim3(TPB), 0, c->stream, P.ne, P.e_ptr, P.e_con, P.e_val,
-                       with_c ? P.cbase : nullptr, mode, wa, P.S, st);
+    LAUNCH(k_sval, nblocks_for((size_t)P.ne, TPB), P.ne, P.e_ptr, P.e_con, P.e_val, with_c ? P.cbase : nullptr, mode, wa, P.S, g);
 }
 
 // one application of the CG operator  out = epilogue(x + (sum_i <A_i, sym(x V^T)> A_i) V)
 // (linSysProduct, lorads_admm.c:376-391); returns #partials in `part`
 int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x, int mode, const double *rhs, double *out,
-                   double *part) {
+                   double *part, Guard g) {
     const bool samp = c->prof && (c->n_matvec % c->prof_every == 0);
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (samp) {
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, c->stream);
     }
-    int g;
+    int grid;
     if (B.diag_only) {
-        switch (lg_for(B.r)) {
-        case 8: g = launch_op_diag<8>(c, B, V, mode, x, rhs, out, part, c->st); break;
-        case 32: g = launch_op_diag<32>(c, B, V, mode, x, rhs, out, part, c->st); break;
-        default: g = launch_op_diag<64>(c, B, V, mode, x, rhs, out, part, c->st); break;
-        }
+        grid = op_diag(c, B, V, mode, x, rhs, out, part, g);
     } else {
-        constr_val(c, B, x, V, 1.0, B.wtmp, c->st);
-        WArgs wa{};
-        wa.w = B.wtmp;
-        sval(c, B, B.pa, false, W_COMPACT, wa, c->st);
+        pairdots(c, B.pa, x, V, B.r, B.T, g);
+        if (B.has_gram) {
+            LAUNCH(k_sgram, nblocks_for((size_t)B.pa.ne, TPB), B.pa.ne, B.g_ptr, B.g_col, B.g_val, B.T, B.pa.S, g);
+        } else {
+            LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T, 1.0, B.wtmp, (int)CV_SET,
+                   B.row_idx, (double *)nullptr, g);
+            WArgs wa{};
+            wa.w = B.wtmp;
+            sval(c, B.pa, false, W_COMPACT, wa, g);
+        }
         if (samp) { hipEventCreate(&e2); hipEventRecord(e2, c->stream); }
-        g = spmm(c, B, B.pa, V, mode, x, rhs, 0.0, out, part, c->st);
+        grid = spmm(c, B, B.pa, V, mode, x, rhs, 0.0, out, part, g);
     }
     if (samp) {
         hipEventRecord(e1, c->stream);
@@ -829,7 +924,7 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
         if (e2) c->pend_sp.push_back({e2, e1});
     }
     c->n_matvec++;
-    return g;
+    return grid;
 }
 
 void drain_events(lorads_hip_ctx *c) {
@@ -850,82 +945,179 @@ void drain_events(lorads_hip_ctx *c) {
     c->pend_sp.clear();
 }
 
-// LORADSUpdateSDPVarOne (lorads_admm.c:428-480): rhs = V - (C + sum_i M1_i A_i) V / rho, then CG on x
-int update_one(lorads_hip_ctx *c, Block &B, double *x, const double *V, double rho, double tol, int maxit, int *iters) {
-    const size_t len = (size_t)B.n * B.r;
-    double *r = c->cr + B.off, *p = c->cp + B.off, *Q = c->cQ + B.off, *rhs = c->rhs + B.off;
-    double *pA = part_slot(c, 0), *pB = part_slot(c, 1), *pC = part_slot(c, 2);
+// ---- one CG solve, split so that it can be enqueued speculatively and resumed
+struct Solve {
+    Block *B;
+    double *x;
+    const double *V;
+    CGState *st;
+    Guard front;   // gate of everything before the iterations ({nullptr, need = previous solve done})
+    size_t len;
+    int gv;
+};
+
+// rhs = V - (C + sum_i M1_i A_i) V / rho, initial residual, state  (lorads_admm.c:432-463, lorads_cgs.c:115,149-172)
+void solve_front(lorads_hip_ctx *c, const Solve &s, double rho, double tol) {
+    Block &B = *s.B;
+    double *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;
+    double *pA = part_slot(c, 0), *pB = part_slot(c, 1);
     WArgs wa{};
     wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.cv = B.cv; wa.row_idx = B.row_idx; wa.rho = rho;
-    HC(hipMemsetAsync(c->st, 0, sizeof(CGState), c->stream));
-    sval(c, B, B.pu, true, W_ADMM, wa, nullptr);
-    int nb1 = spmm(c, B, B.pu, V, OP_RHS, nullptr, nullptr, rho, rhs, pB, nullptr); // ||rhs||_1 partials
-    // initial residual (lorads_cgs.c:149-160)
-    int na = apply_operator(c, B, V, x, OP_RES, rhs, r, pA);
-    hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_INIT, pA, na, pB, nb1, tol, maxit);
-    const int gv = grid1d(len);
-    hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_INIT, r, p);
-    CGState h{};
-    int k = 0;
-    int chunk = std::max(2, std::min(B.cg_iter_last > 0 ? B.cg_iter_last : 8, 32));
-    for (;;) {
-        for (int t = 0; t < chunk && k < maxit; ++t, ++k) {
-            int npq = apply_operator(c, B, V, p, OP_CG, nullptr, Q, pA);
-            hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, pA, npq, x, r, p, Q, pC);
-            hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_ITER, pC, gv, nullptr, 0, tol, maxit);
-            if (k % 20 == 0) { // restart with the true residual (lorads_cgs.c:195-211), including k = 0
-                int nr = apply_operator(c, B, V, x, OP_RES, rhs, r, pA);
-                hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(TPB), 0, c->stream, c->st, (int)CHK_RESTART, pA, nr, nullptr, 0, tol,
-                                   maxit);
-                hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_RESTART, r, p);
-            } else {
-                hipLaunchKernelGGL(k_cg_dir, dim3(gv), dim3(TPB), 0, c->stream, len, c->st, (int)DIR_BETA, r, p);
-            }
-        }
-        HC(hipMemcpyAsync(&h, c->st, sizeof(CGState), hipMemcpyDeviceToHost, c->stream));
-        HC(hipStreamSynchronize(c->stream));
-        if (h.done || k >= maxit) break;
-        chunk = std::max(2, std::min(chunk, 16));
+    sval(c, B.pu, true, W_ADMM, wa, s.front);
+    const int nb1 = spmm(c, B, B.pu, s.V, OP_RHS, nullptr, nullptr, rho, rhs, pB, s.front);
+    const int na = apply_operator(c, B, s.V, s.x, OP_RES, rhs, r, pA, s.front);
+    LAUNCH(k_cg_init, s.gv, s.len, s.st, pA, na, pB, nb1, tol, r, p, s.front);
+}
+// body of CG iteration k up to and including the convergence test (lorads_cgs.c:180-194)
+void solve_iter_body(lorads_hip_ctx *c, const Solve &s, double tol, int maxit) {
+    Block &B = *s.B;
+    double *r = c->cr + B.off, *p = c->cp + B.off, *Q = c->cQ + B.off;
+    double *pA = part_slot(c, 0), *pC = part_slot(c, 2);
+    const Guard g{&s.st->done, s.front.need};
+    const int npq = apply_operator(c, B, s.V, p, OP_CG, nullptr, Q, pA, g);
+    LAUNCH(k_cg_update, s.gv, s.len, s.st, pA, npq, s.x, r, p, Q, pC, g);
+    LAUNCH(k_cg_check, 1, s.st, (int)CHK_ITER, pC, s.gv, tol, maxit, g);
+}
+// tail of CG iteration k: restart with the true residual when k % 20 == 0 (incl. k = 0), new direction (:195-228)
+void solve_iter_tail(lorads_hip_ctx *c, const Solve &s, int k, double tol, int maxit) {
+    Block &B = *s.B;
+    double *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;
+    double *pA = part_slot(c, 0);
+    const Guard g{&s.st->done, s.front.need};
+    if (k % 20 == 0) {
+        const int nr = apply_operator(c, B, s.V, s.x, OP_RES, rhs, r, pA, g);
+        LAUNCH(k_cg_check, 1, s.st, (int)CHK_RESTART, pA, nr, tol, maxit, g);
+        LAUNCH(k_cg_dir, s.gv, s.len, s.st, (int)DIR_RESTART, r, p, g);
+    } else {
+        LAUNCH(k_cg_dir, s.gv, s.len, s.st, (int)DIR_BETA, r, p, g);
     }
-    if (h.nan) fprintf(stderr, "lorads_hip: NaN residual in CG (block n=%d)\n", B.n);
-    if (h.done != 2) B.cg_iter_last = h.iter; // an immediate exit leaves the stale count (reference quirk)
-    *iters = B.cg_iter_last;
-    c->n_cg_it += (h.done == 2 ? 0 : h.iter);
-    c->n_solves++;
-    return 0;
+}
+// iterations [k0, k1): bodies, with tails between them (the tail of the last one is left to a resume)
+void solve_iters(lorads_hip_ctx *c, const Solve &s, int k0, int k1, double tol, int maxit) {
+    for (int k = k0; k < k1; ++k) {
+        if (k > k0) solve_iter_tail(c, s, k - 1, tol, maxit);
+        solve_iter_body(c, s, tol, maxit);
+    }
+}
+// constrVal[k] <- A_k(sym(U V^T)) and constrValSum += new - old (lorads_alg_common.c:199-203)
+void refresh_after_solve(lorads_hip_ctx *c, Block &B, const int *need) {
+    constr_val(c, B, c->U + B.off, c->V + B.off, 1.0, B.cv, CV_DELTA, c->csum, Guard{nullptr, need});
 }
 
-int refresh_constr_all(lorads_hip_ctx *c, const double *X, const double *Y) {
-    HC(hipMemsetAsync(c->csum, 0, sizeof(double) * (size_t)(c->m + 2), c->stream));
-    for (auto &B : c->blk) {
-        constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, nullptr);
-        scatter_add(c, B, B.cv, 1.0, c->csum);
-    }
-    return 0;
-}
-
-int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) {
-    HC(hipMemcpyAsync(out, c->scal + first, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+int read_states(lorads_hip_ctx *c) {
+    HC(hipMemcpyAsync(c->h_st, c->st, sizeof(CGState) * (size_t)(2 * c->nb), hipMemcpyDeviceToHost, c->stream));
+    HC(hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
     HC(hipStreamSynchronize(c->stream));
     return 0;
 }
 
+Solve make_solve(lorads_hip_ctx *c, int k, int half, const int *need) {
+    Block &B = c->blk[k];
+    Solve s;
+    s.B = &B;
+    s.x = (half == 0 ? c->U : c->V) + B.off;
+    s.V = (half == 0 ? c->V : c->U) + B.off;
+    s.st = c->st + 2 * k + half;
+    s.front = Guard{nullptr, need};
+    s.len = (size_t)B.n * B.r;
+    s.gv = grid1d(s.len);
+    return s;
+}
+
+// LORADSUpdateSDPVar (lorads_alg_common.c:187-215) for all cones of this context, enqueued speculatively
+// from stage `first` (stage = 2*cone + half); `resume_iter` >= 0 resumes that stage's CG after that many
+// completed iterations
+void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, double tol, int maxit) {
+    for (int stg = first; stg < 2 * c->nb; ++stg) {
+        const int k = stg / 2, half = stg % 2;
+        const int *need = stg == 0 ? nullptr : &c->st[stg - 1].done;
+        Solve s = make_solve(c, k, half, need);
+        Block &B = *s.B;
+        if (stg == first && resume_iter >= 0) {
+            const int more = std::max(2, std::min(resume_iter, 16));
+            if (resume_iter > 0) solve_iter_tail(c, s, resume_iter - 1, tol, maxit);
+            solve_iters(c, s, resume_iter, std::min(resume_iter + more, maxit), tol, maxit);
+        } else {
+            solve_front(c, s, rho, tol);
+            solve_iters(c, s, 0, std::min(B.spec[half], maxit), tol, maxit);
+        }
+        refresh_after_solve(c, B, &s.st->done);
+    }
+}
+
+// after a sync: first stage >= first whose solve is not finished, or -1
+int first_unfinished(lorads_hip_ctx *c, int first) {
+    for (int stg = first; stg < 2 * c->nb; ++stg)
+        if (c->h_st[stg].done == 0) return stg;
+    return -1;
+}
+
+// objective + DIMACS refresh (calObj_admm + LORADSCalDualObj + updateDimacsADMM, lorads_admm.c:79-81):
+// R = (U+V)/2 (pair UV), constrVal <- A(R R^T), constrValSum, then scal[0..2] = {||b-sum||^2, b.lambda, <C,RR^T>}
+int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need) {
+    const Guard g{nullptr, need};
+    if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, g);
+    const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
+    if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
+    LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
+    for (auto &B : c->blk) {
+        constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
+        const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
+        if (go) LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, 1, c->scal + 2, g);
+    }
+    if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part] per evaluation
+        HC(hipMemcpyAsync(c->csum + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
+        HC(hipMemcpyAsync(c->scal + 2, c->csum + c->m, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    LAUNCH(k_eval_final, 1, c->m, c->b, c->csum, c->lambda, c->scal, g);
+    return 0;
+}
+
+int read_scalars_at(lorads_hip_ctx *c, const double *dptr, int count, double *out) {
+    HC(hipMemcpyAsync(c->h_scal + 32, dptr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HC(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_scal + 32, sizeof(double) * (size_t)count);
+    return 0;
+}
+int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) { return read_scalars_at(c, c->scal + first, count, out); }
+
 // flat dot -> device scalar slot (+ cross-rank sum)
 int dot_to_slot(lorads_hip_ctx *c, const double *x, const double *y, int slot) {
     int g = grid1d(c->all_elem);
-    hipLaunchKernelGGL(k_dot, dim3(g), dim3(TPB), 0, c->stream, c->all_elem, x, y, part_slot(c, 3));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 3), g, c->scal + slot);
+    LAUNCH(k_dot, g, c->all_elem, x, y, part_slot(c, 3));
+    LAUNCH(k_finalize, 1, part_slot(c, 3), g, 1.0, 0, c->scal + slot, NOGUARD);
     return allreduce_dev(c, c->scal + slot, 1);
 }
 
-int objective(lorads_hip_ctx *c, const double *X, const double *Y, int slot) {
-    // sum over cones of <C_k, sym(X_k Y_k^T)> -> scal[slot] (local part)
-    HC(hipMemsetAsync(c->scal + slot, 0, sizeof(double), c->stream));
-    for (auto &B : c->blk) {
-        int g = obj_partials(c, B, X + B.off, Y + B.off, part_slot(c, 4));
-        if (g == 0) continue;
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 4), g, c->scal + 32);
-        hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, 1.0, c->scal + 32, c->scal + slot);
+// collect the sweep results after all stages are finished
+int finish_sweep(lorads_hip_ctx *c, int *iters) {
+    int tot = 0;
+    for (int stg = 0; stg < 2 * c->nb; ++stg) {
+        Block &B = c->blk[stg / 2];
+        const CGState &h = c->h_st[stg];
+        if (h.nan) fprintf(stderr, "lorads_hip: NaN residual in CG (cone %d)\n", stg / 2);
+        if (h.done != 2) B.cg_iter_last = h.iter; // an immediate exit leaves the stale count (reference quirk)
+        tot += B.cg_iter_last;
+        B.spec[stg % 2] = h.done == 2 ? 0 : h.iter;
+        c->n_cg_it += (h.done == 2 ? 0 : h.iter);
+        c->n_solves++;
+    }
+    *iters = tot;
+    return 0;
+}
+
+int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
+    int first = 0, resume = -1;
+    for (;;) {
+        enqueue_sweep(c, first, resume, rho, tol, maxit);
+        if (with_eval && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
+        if (read_states(c)) return 1;
+        const int stg = first_unfinished(c, first);
+        if (stg < 0) break;
+        first = stg;
+        resume = c->h_st[stg].iter;
+        c->n_resume++;
     }
     return 0;
 }
@@ -952,17 +1144,19 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
-        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)8 * MAXPART) || dalloc(&c->scal, 64) ||
-        dalloc(&c->st, 1) || dalloc(&c->ring_ab, (size_t)2 * c->L)) {
+        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) || dalloc(&c->scal, 64) ||
+        dalloc(&c->st, (size_t)2 * c->nb) || dalloc(&c->ring_ab, (size_t)2 * c->L)) {
         lorads_hip_destroy(c);
         return 1;
     }
+    HC(hipHostMalloc((void **)&c->h_st, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
+    HC(hipHostMalloc((void **)&c->h_scal, sizeof(double) * 64));
     HC(hipMemset(c->lambda, 0, sizeof(double) * (size_t)std::max(c->m, 1)));
     HC(hipMemset(c->csum, 0, sizeof(double) * (size_t)(c->m + 2)));
     HC(hipMemset(c->q12, 0, sizeof(double) * (size_t)(2 * c->m + 2)));
     HC(hipMemset(c->scal, 0, sizeof(double) * 64));
     HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
-    HC(hipMemset(c->st, 0, sizeof(CGState)));
+    HC(hipMemset(c->st, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
     HC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -975,11 +1169,14 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     for (auto &B : c->blk) {
         B.pa.release(); B.pu.release();
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.cv); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.g_ptr); hipFree(B.g_col);
+        hipFree(B.g_val);
     }
     free_factors(c);
     hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->scal); hipFree(c->st);
     hipFree(c->ring_ab);
+    if (c->h_st) hipHostFree(c->h_st);
+    if (c->h_scal) hipHostFree(c->h_scal);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -997,22 +1194,22 @@ int lorads_hip_set_allreduce(lorads_hip_ctx *c, lorads_hip_allreduce_fn fn, void
 
 int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
     const double *X = pair == LORADS_HIP_PAIR_RR ? c->R : c->U, *Y = pair == LORADS_HIP_PAIR_RR ? c->R : c->V;
-    if (refresh_constr_all(c, X, Y)) return 1;
+    LAUNCH(k_zero, grid1d((size_t)c->m + 2), (size_t)c->m + 2, c->csum, NOGUARD);
+    for (auto &B : c->blk) constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, CV_ADD, c->csum, NOGUARD);
     return allreduce_dev(c, c->csum, c->m);
 }
 
 int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
-    HC(hipMemsetAsync(c->scal + 1, 0, sizeof(double), c->stream));
+    LAUNCH(k_zero, 1, (size_t)1, c->scal + 8, NOGUARD);
     for (auto &B : c->blk) {
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
-        sval(c, B, B.pu, true, W_ALM, wa, nullptr);
-        int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), nullptr);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 0), g, c->scal + 32);
-        hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, 1.0, c->scal + 32, c->scal + 1);
+        sval(c, B.pu, true, W_ALM, wa, NOGUARD);
+        int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), NOGUARD);
+        LAUNCH(k_finalize, 1, part_slot(c, 0), g, 1.0, 1, c->scal + 8, NOGUARD);
     }
-    if (allreduce_dev(c, c->scal + 1, 1)) return 1;
-    return read_scalars(c, 1, 1, lag);
+    if (allreduce_dev(c, c->scal + 8, 1)) return 1;
+    return read_scalars(c, 8, 1, lag);
 }
 
 int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
@@ -1020,62 +1217,53 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     const int gv = grid1d(n);
     double *D = c->U;
     if (inner == 0) {
-        hipLaunchKernelGGL(k_scale_copy, dim3(gv), dim3(TPB), 0, c->stream, n, -1.0, c->G, D);
+        LAUNCH(k_scale_copy, gv, n, -1.0, c->G, D);
     } else {
         double *q = c->Dtmp;
         HC(hipMemcpyAsync(q, c->G, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
         const int nn = inner <= c->L - 1 ? inner : c->L;
         int node = (c->head - 1 + c->L) % c->L;
-        double *dot = c->scal + 8, *coef = c->scal + 9;
+        double *dot = c->scal + 9, *coef = c->scal + 10;
         for (int t = 0; t < nn; ++t) {
-            if (dot_to_slot(c, c->ring[node].s, q, 8)) return 1;
+            if (dot_to_slot(c, c->ring[node].s, q, 9)) return 1;
             hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_ALPHA, dot, c->ring_ab + 2 * node,
                                c->ring_ab + 2 * node + 1, coef);
-            hipLaunchKernelGGL(k_axpy_dev, dim3(gv), dim3(TPB), 0, c->stream, n, coef, c->ring[node].y, q);
+            LAUNCH(k_axpy_dev, gv, n, coef, c->ring[node].y, q);
             node = (node - 1 + c->L) % c->L;
         }
         node = (node + 1) % c->L;
         for (int t = 0; t < nn; ++t) {
-            if (dot_to_slot(c, c->ring[node].y, q, 8)) return 1;
+            if (dot_to_slot(c, c->ring[node].y, q, 9)) return 1;
             hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_W, dot, c->ring_ab + 2 * node,
                                c->ring_ab + 2 * node + 1, coef);
-            hipLaunchKernelGGL(k_axpy_dev, dim3(gv), dim3(TPB), 0, c->stream, n, coef, c->ring[node].s, q);
+            LAUNCH(k_axpy_dev, gv, n, coef, c->ring[node].s, q);
             node = (node + 1) % c->L;
         }
-        hipLaunchKernelGGL(k_scale_copy, dim3(gv), dim3(TPB), 0, c->stream, n, -1.0, q, D);
+        LAUNCH(k_scale_copy, gv, n, -1.0, q, D);
     }
-    if (dot_to_slot(c, D, c->G, 10)) return 1;
-    hipLaunchKernelGGL(k_use_grad, dim3(gv), dim3(TPB), 0, c->stream, n, c->scal + 10, c->G, D);
+    if (dot_to_slot(c, D, c->G, 11)) return 1;
+    LAUNCH(k_use_grad, gv, n, c->scal + 11, c->G, D);
     return 0;
 }
 
 int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
     const int m = c->m;
-    HC(hipMemsetAsync(c->q12, 0, sizeof(double) * (size_t)(2 * m + 2), c->stream));
+    LAUNCH(k_zero, grid1d((size_t)2 * m + 2), (size_t)2 * m + 2, c->q12, NOGUARD);
     for (int pass = 0; pass < 2; ++pass) {
         const double *X = pass == 0 ? c->R : c->U; // D lives in U
         const double scale = pass == 0 ? 2.0 : 1.0;
         for (auto &B : c->blk) {
-            constr_val(c, B, X + B.off, c->U + B.off, 1.0, B.cv, nullptr);
-            scatter_add(c, B, B.cv, scale, c->q12 + (size_t)pass * m);
-            int g = obj_partials(c, B, X + B.off, c->U + B.off, part_slot(c, 4));
-            if (g == 0) continue;
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 4), g, c->scal + 32);
-            hipLaunchKernelGGL(k_axpy, dim3(1), dim3(1), 0, c->stream, (size_t)1, scale, c->scal + 32, c->q12 + 2 * m + pass);
+            constr_val(c, B, X + B.off, c->U + B.off, scale, B.cv, CV_ADD, c->q12 + (size_t)pass * m, NOGUARD);
+            int g = obj_partials(c, B, X + B.off, c->U + B.off, part_slot(c, 4), NOGUARD);
+            if (g) LAUNCH(k_finalize, 1, part_slot(c, 4), g, scale, 1, c->q12 + 2 * m + pass, NOGUARD);
         }
     }
     if (allreduce_dev(c, c->q12, 2 * m + 2)) return 1;
-    HC(hipMemcpyAsync(p12, c->q12 + 2 * m, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    HC(hipStreamSynchronize(c->stream));
-    return 0;
+    return read_scalars_at(c, c->q12 + 2 * m, 2, p12);
 }
 
 int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
-    const int g = std::min(grid1d((size_t)c->m), 64);
-    hipLaunchKernelGGL(k_linesearch, dim3(g), dim3(TPB), 0, c->stream, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12,
-                       c->q12 + c->m, part_slot(c, 5));
-    for (int t = 0; t < 5; ++t)
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 5) + (size_t)t * g, g, c->scal + 16 + t);
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
     double s[5];
     if (read_scalars(c, 16, 5, s)) return 1;
     k[0] = rho * s[0] / 2;              // rho ||q2||^2 / 2
@@ -1086,78 +1274,75 @@ int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, d
 }
 
 int lorads_hip_set_y_as_neg_grad(lorads_hip_ctx *c) {
-    hipLaunchKernelGGL(k_scale_copy, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, -1.0, c->G,
-                       c->ring[c->head].y);
+    LAUNCH(k_scale_copy, grid1d(c->all_elem), c->all_elem, -1.0, c->G, c->ring[c->head].y);
     return 0;
 }
 
 int lorads_hip_alm_update_var(lorads_hip_ctx *c, double tau) {
-    hipLaunchKernelGGL(k_axpy, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, tau, c->U, c->R);
-    hipLaunchKernelGGL(k_csum_step, dim3(nblocks_for((size_t)c->m, TPB)), dim3(TPB), 0, c->stream, c->m, tau, c->q12, c->q12 + c->m,
-                       c->csum);
+    LAUNCH(k_axpy, grid1d(c->all_elem), c->all_elem, tau, c->U, c->R);
+    LAUNCH(k_csum_step, nblocks_for((size_t)c->m, TPB), c->m, tau, c->q12, c->q12 + c->m, c->csum);
     return 0;
 }
 
 int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
     Ring &h = c->ring[c->head];
-    hipLaunchKernelGGL(k_his_two, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, tau, c->U, c->G, h.s, h.y);
-    if (dot_to_slot(c, h.y, h.s, 8)) return 1;
-    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 8, c->ring_ab + 2 * c->head,
-                       c->ring_ab + 2 * c->head + 1, c->scal + 9);
+    LAUNCH(k_his_two, grid1d(c->all_elem), c->all_elem, tau, c->U, c->G, h.s, h.y);
+    if (dot_to_slot(c, h.y, h.s, 9)) return 1;
+    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 9, c->ring_ab + 2 * c->head,
+                       c->ring_ab + 2 * c->head + 1, c->scal + 10);
     c->head = (c->head + 1) % c->L;
     return 0;
 }
 
 int lorads_hip_update_dimacs(lorads_hip_ctx *c, int32_t pair, double *err1) {
-    if (pair == LORADS_HIP_PAIR_UV)
-        hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
-    if (refresh_constr_all(c, c->R, c->R)) return 1;
-    if (allreduce_dev(c, c->csum, c->m)) return 1;
-    const int g = std::min(grid1d((size_t)c->m), 256);
-    hipLaunchKernelGGL(k_vio, dim3(g), dim3(TPB), 0, c->stream, c->m, c->b, c->csum, part_slot(c, 6));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 6), g, c->scal + 2);
-    double s;
-    if (read_scalars(c, 2, 1, &s)) return 1;
-    *err1 = std::sqrt(s) / (1 + c->b_nrm1);
+    if (enqueue_eval(c, pair, nullptr)) return 1;
+    double s[3];
+    if (read_scalars(c, 0, 3, s)) return 1;
+    *err1 = std::sqrt(s[0]) / (1 + c->b_nrm1);
     return 0;
 }
 
 int lorads_hip_cal_obj(lorads_hip_ctx *c, int32_t pair, double *pobj) {
-    if (pair == LORADS_HIP_PAIR_UV)
-        hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
-    if (objective(c, c->R, c->R, 3)) return 1;
+    if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, NOGUARD);
+    LAUNCH(k_zero, 1, (size_t)1, c->scal + 3, NOGUARD);
+    for (auto &B : c->blk) {
+        int g = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), NOGUARD);
+        if (g) LAUNCH(k_finalize, 1, part_slot(c, 4), g, 1.0, 1, c->scal + 3, NOGUARD);
+    }
     if (allreduce_dev(c, c->scal + 3, 1)) return 1;
     return read_scalars(c, 3, 1, pobj);
 }
 
 int lorads_hip_admm_update_var(lorads_hip_ctx *c, double rho, double tol, int32_t maxit, int32_t *iters) {
-    int tot = 0;
-    for (auto &B : c->blk) {
-        double *U = c->U + B.off, *V = c->V + B.off;
-        for (int half = 0; half < 2; ++half) {
-            int it = 0;
-            if (update_one(c, B, half == 0 ? U : V, half == 0 ? V : U, rho, tol, maxit, &it)) return 1;
-            tot += it;
-            // running sum bookkeeping of LORADSUpdateSDPVar (lorads_alg_common.c:199-203)
-            scatter_add(c, B, B.cv, -1.0, c->csum);
-            constr_val(c, B, U, V, 1.0, B.cv, nullptr);
-            scatter_add(c, B, B.cv, 1.0, c->csum);
-        }
-    }
-    *iters = tot;
+    if (run_sweep(c, rho, tol, maxit, false)) return 1;
+    int its = 0;
+    finish_sweep(c, &its);
+    *iters = its;
+    return 0;
+}
+
+// fused ADMM step: admmUpdateVar + calObj_admm + LORADSCalDualObj + updateDimacsADMM with ONE host
+// synchronisation (lorads_admm.c:76-81); out = {cg iterations, <C,RR^T>, b.lambda, err1}
+int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxit, double out[4]) {
+    if (run_sweep(c, rho, tol, maxit, true)) return 1;
+    int its = 0;
+    finish_sweep(c, &its);
+    out[0] = its;
+    out[1] = c->h_scal[2];
+    out[2] = c->h_scal[1];
+    out[3] = std::sqrt(c->h_scal[0]) / (1 + c->b_nrm1);
     return 0;
 }
 
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
-    hipLaunchKernelGGL(k_dual_update, dim3(nblocks_for((size_t)c->m, TPB)), dim3(TPB), 0, c->stream, c->m, rho, c->b, c->csum,
-                       c->lambda);
+    LAUNCH(k_dual_update, nblocks_for((size_t)c->m, TPB), c->m, rho, c->b, c->csum, c->lambda);
     return 0;
 }
 
 int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
     const int g = std::min(grid1d((size_t)c->m), 256);
-    hipLaunchKernelGGL(k_dot, dim3(g), dim3(TPB), 0, c->stream, (size_t)c->m, c->b, c->lambda, part_slot(c, 7));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, c->stream, part_slot(c, 7), g, c->scal + 4);
+    LAUNCH(k_dot, g, (size_t)c->m, c->b, c->lambda, part_slot(c, 7));
+    LAUNCH(k_finalize, 1, part_slot(c, 7), g, 1.0, 0, c->scal + 4, NOGUARD);
     return read_scalars(c, 4, 1, dobj);
 }
 
@@ -1168,17 +1353,17 @@ int lorads_hip_alm_to_admm(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
-    hipLaunchKernelGGL(k_average, dim3(grid1d(c->all_elem)), dim3(TPB), 0, c->stream, c->all_elem, c->U, c->V, c->R);
+    LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, NOGUARD);
     HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
 int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
     for (auto &B : c->blk) {
-        if (B.nc) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)B.nc)), dim3(TPB), 0, c->stream, (size_t)B.nc, s, B.c_val);
-        if (B.pu.ne) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)B.pu.ne)), dim3(TPB), 0, c->stream, (size_t)B.pu.ne, s, B.pu.cbase);
+        if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
+        if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
     }
-    if (c->m) hipLaunchKernelGGL(k_scale, dim3(grid1d((size_t)c->m)), dim3(TPB), 0, c->stream, (size_t)c->m, s, c->lambda);
+    if (c->m) LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, s, c->lambda);
     return 0;
 }
 
@@ -1248,6 +1433,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
         for (int k = 0; k < c->nb; ++k)
             if (lorads_hip_set_mat(c, whichs[a], k, keep[a][k].data())) return 1;
     HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
+    HC(hipDeviceSynchronize());
     return 0;
 }
 
@@ -1256,7 +1442,7 @@ int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
     drain_events(c);
     c->prof = enable;
     c->prof_every = std::max(1, every);
-    c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = 0;
+    c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = c->n_resume = 0;
     c->ms_samp = c->ms_samp_spmm = 0;
     return 0;
 }
@@ -1265,7 +1451,7 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
     HC(hipStreamSynchronize(c->stream));
     drain_events(c);
     s[0] = (double)c->n_matvec;
-    s[1] = c->n_samp ? c->ms_samp / c->n_samp * c->n_matvec : 0.0;
+    s[1] = (double)c->n_resume;
     s[2] = (double)c->n_cg_it;
     s[3] = (double)c->n_solves;
     s[4] = (double)c->n_samp;

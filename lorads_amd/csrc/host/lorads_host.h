@@ -133,6 +133,9 @@ typedef struct lrd_backend {
     int (*get_vec)(void *ctx, int which, double *v);
     int (*set_allreduce)(void *ctx, lrd_allreduce_fn fn, void *user);
     void (*destroy)(void *ctx);
+    /* OPTIONAL (may be NULL): admm_update_var + cal_obj(UV) + cal_dual_obj + update_dimacs(UV) in one
+     * call, same order and results (lorads_admm.c:76-81); out = {cg iterations, pobj, dobj, err1} */
+    int (*admm_step)(void *ctx, double rho, double cg_tol, int cg_max_iter, double out[4]);
 } lrd_backend;
 
 /* iteration states, as the reference's lorads_alm_state / lorads_admm_state
@@ -166,6 +169,7 @@ typedef struct {
     void *allreduce_user;
     double t_alm, t_admm;
     int admm_iters_first, cg_iters_first;
+    int use_fused_step; /* 1: use lrd_backend.admm_step when the table has it */
 } lrd_solver;
 
 /* ---- params / problem ---- */

@@ -117,6 +117,12 @@ int lrd_session_set_allreduce(lrd_session *s, lrd_allreduce_fn fn, void *user) {
     return s->be.set_allreduce(s->be.ctx, fn, user);
 }
 
+int lrd_session_use_fused_step(lrd_session *s, int on) {
+    if (!s->have_sol) return 1;
+    s->sol.use_fused_step = on;
+    return 0;
+}
+
 int lrd_session_solve(lrd_session *s) { return s->have_sol ? lrd_solve(&s->par, &s->sol) : 1; }
 
 /* finer-grained drivers for tests / bench */

@@ -122,6 +122,7 @@ int lrd_solver_init(lrd_solver *s, lrd_problem *prob, lrd_backend *be, const lrd
     s->scaleObjHis = 1.0;
     s->max_alm_sub_iter = 5000;
     s->status = LRD_UNKNOWN;
+    s->use_fused_step = 1;
     return 0;
 }
 
@@ -419,11 +420,23 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
         /* CG tolerance from the (possibly stale, quirk Q5) l1 infeasibility: 1e-2 vs 1e-4 */
         double cg_tol = LMIN(d->l_1_primal_infeasibility * (reopt ? 1e-4 : 1e-2), 1e-8);
         int cg_its = 0;
-        be->admm_update_var(cx, d->rho, cg_tol, cg_max, &cg_its);
-        s->cgIter += cg_its;
-        d->cg_iter = s->cgIter;
-        refresh_obj(s, LRD_PAIR_UV);
-        refresh_dimacs(s, LRD_PAIR_UV);
+        if (be->admm_step && s->use_fused_step) {
+            double o[4];
+            be->admm_step(cx, d->rho, cg_tol, cg_max, o);
+            cg_its = (int)o[0];
+            s->pObjVal = o[1] / s->scaleObjHis;
+            s->dObjVal = o[2] / s->scaleObjHis;
+            s->err_constr_l1 = o[3];
+            s->err_pdgap = fabs(s->pObjVal - s->dObjVal) / (1 + fabs(s->pObjVal) + fabs(s->dObjVal));
+            s->cgIter += cg_its;
+            d->cg_iter = s->cgIter;
+        } else {
+            be->admm_update_var(cx, d->rho, cg_tol, cg_max, &cg_its);
+            s->cgIter += cg_its;
+            d->cg_iter = s->cgIter;
+            refresh_obj(s, LRD_PAIR_UV);
+            refresh_dimacs(s, LRD_PAIR_UV);
+        }
         admm_pull_state(s, reopt); /* the first-pass loop does not refresh l1 here (lorads_admm.c:82-85) */
         d->l_inf_primal_infeasibility = inf_from_l1(s, s->err_constr_l1);
         if (reopt) d->l_2_primal_infeasibility = l2_from_l1(s, s->err_constr_l1);

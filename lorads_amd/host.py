@@ -53,6 +53,7 @@ class BackendStruct(C.Structure):
         ("get_vec", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _dp)),
         ("set_allreduce", C.CFUNCTYPE(C.c_int, C.c_void_p, ALLREDUCE_FN, C.c_void_p)),
         ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
+        ("admm_step", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, _dp)),
     ]
 
 
@@ -116,6 +117,16 @@ class Backend:
         it = C.c_int()
         _check(self._s.admm_update_var(self._s.ctx, rho, cg_tol, cg_max_iter, C.byref(it)), "admm_update_var")
         return it.value
+
+    @property
+    def has_admm_step(self):
+        return bool(self._s.admm_step)
+
+    def admm_step(self, rho, cg_tol, cg_max_iter=800):
+        """fused ADMM iteration (optional slot): returns (cg_iters, pobj, dobj, err1)"""
+        o = (C.c_double * 4)()
+        _check(self._s.admm_step(self._s.ctx, rho, cg_tol, cg_max_iter, o), "admm_step")
+        return int(o[0]), o[1], o[2], o[3]
 
     def update_dual_var(self, rho):
         _check(self._s.update_dual_var(self._s.ctx, rho), "update_dual_var")
@@ -334,6 +345,10 @@ class Session:
         cb = ALLREDUCE_FN(_cb)
         self._keep.append(cb)
         _check(self.lib.lrd_session_set_allreduce(self.h, cb, None), "set_allreduce")
+
+    def use_fused_step(self, on):
+        self.lib.lrd_session_use_fused_step.argtypes = [C.c_void_p, C.c_int]
+        _check(self.lib.lrd_session_use_fused_step(self.h, int(on)), "use_fused_step")
 
     def solve(self):
         _check(self.lib.lrd_session_solve(self.h), "solve")

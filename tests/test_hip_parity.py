@@ -162,3 +162,67 @@ def test_linearity_and_symmetry_of_operator_fullsize(built):
         assert np.isclose(o2, 4 * o1, rtol=1e-11)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name", ["maxcut100", "rand120", "blk4x60", "coupled3x70", "theta30"])
+def test_fused_step_equals_separate_calls(built, name):
+    """lorads_hip_admm_step (one sync, speculative enqueue with gates) must give exactly what the four
+    separate entry points give, also when the speculation misses (first iterations, changing tol)."""
+    g = common.golden_trace(name)
+    sessions = [common.hip_session(common.instance_path(name)) for _ in range(2)]
+    try:
+        rank_warm = [int(x) for x in g["rank_warm"]]
+        for s in sessions:
+            if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                s.be.resize_rank(rank_warm)
+            for k in range(s.nblk):
+                n, r = s.block_shape(k)
+                s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+            s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+            s.be.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+            s.be.cal_obj(host.PAIR_UV)
+            s.be.update_dimacs(host.PAIR_UV)
+        a, b = sessions
+        rho = float(g["admm_rho"][0])
+        for it, tol in enumerate([1e-8, 1e-8, 1e-12, 1e-6, 1e-14, 1e-9]):
+            ca, pa, da, ea = a.be.admm_step(rho, tol, 800)
+            cb = b.be.admm_update_var(rho, tol, 800)
+            pb, db, eb = b.be.cal_obj(host.PAIR_UV), b.be.cal_dual_obj(), b.be.update_dimacs(host.PAIR_UV)
+            assert ca == cb, (it, ca, cb)
+            assert pa == pb and da == db and ea == eb, (it, pa, pb, da, db, ea, eb)
+            for k in range(a.nblk):
+                assert np.array_equal(a.be.get_mat(host.MAT_U, k), b.be.get_mat(host.MAT_U, k))
+                assert np.array_equal(a.be.get_mat(host.MAT_V, k), b.be.get_mat(host.MAT_V, k))
+            a.be.update_dual_var(rho)
+            b.be.update_dual_var(rho)
+        # and against the reference's own numbers for the first iterations (tol as in the trace)
+    finally:
+        for s in sessions:
+            s.close()
+
+
+def test_cg_long_solve_with_restarts(built):
+    """a solve that needs > 20 iterations exercises the k % 20 restart and the resume path; compared
+    with the CPU oracle's CG (same quirks) on the same input"""
+    path = common.instance_path("maxcut800")
+    hs, os_ = _pair(path)
+    try:
+        rng = np.random.default_rng(3)
+        n, r = hs.block_shape(0)
+        U = rng.standard_normal((n, r))
+        V = rng.standard_normal((n, r)) * 3
+        for s in (hs, os_):
+            s.be.set_mat(host.MAT_U, 0, U)
+            s.be.set_mat(host.MAT_V, 0, V)
+            s.be.set_vec(host.VEC_LAMBDA, np.linspace(-1, 1, s.m))
+            s.be.init_constr(host.PAIR_UV)
+        ia = hs.be.admm_update_var(0.3, 1e-13, 800)
+        ib = os_.be.admm_update_var(0.3, 1e-13, 800)
+        assert ib > 40, ib
+        assert abs(ia - ib) <= max(2, 0.05 * ib), (ia, ib)
+        Ua, Ub = hs.be.get_mat(host.MAT_U, 0), os_.be.get_mat(host.MAT_U, 0)
+        assert np.allclose(Ua, Ub, rtol=0, atol=1e-7 * np.abs(Ub).max())
+    finally:
+        hs.close()
+        os_.close()
