@@ -224,7 +224,10 @@ __device__ __forceinline__ double weight_of(int mode, const WArgs &a, int i) {
 // S_e = [cbase_e] + sum over the constraints touching e of weight_i * a
 __global__ __launch_bounds__(TPB) void k_sval(int ne, const int *__restrict__ e_ptr, const int *__restrict__ e_con,
                                               const double *__restrict__ e_val, const double *__restrict__ cbase, int mode,
-                                              WArgs wa, double *__restrict__ S, Guard g) {
+                                              WArgs wa, double *__restrict__ S, Guard g, CGState *reset, int nreset) {
+    // first kernel of a sweep: mark every later stage "not finished" (stage 0 itself is reset by its k_cg_init,
+    // nothing before that reads it)
+    if (reset && blockIdx.x == 0 && threadIdx.x < nreset) reset[threadIdx.x].done = 0;
     if (blocked(g)) return;
     const int e = blockIdx.x * TPB + threadIdx.x;
     if (e >= ne) return;
@@ -232,16 +235,19 @@ __global__ __launch_bounds__(TPB) void k_sval(int ne, const int *__restrict__ e_
     for (int t = e_ptr[e]; t < e_ptr[e + 1]; ++t) s += weight_of(mode, wa, e_con[t]) * e_val[t];
     S[e] = s;
 }
-// S = G T with G = A A^T over pattern entries (w = A T and S = A^T w in one pass)
+// S = G T with G = A A^T over pattern entries (w = A T and S = A^T w in one pass); 8 lanes per entry so
+// that the dependent (index -> T) loads of one Gram row are in flight together
 __global__ __launch_bounds__(TPB) void k_sgram(int ne, const int *__restrict__ g_ptr, const int *__restrict__ g_col,
                                                const double *__restrict__ g_val, const double *__restrict__ T,
                                                double *__restrict__ S, Guard g) {
     if (blocked(g)) return;
-    const int e = blockIdx.x * TPB + threadIdx.x;
-    if (e >= ne) return;
+    const int e = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
+    const bool act = e < ne;
     double s = 0.0;
-    for (int t = g_ptr[e]; t < g_ptr[e + 1]; ++t) s += g_val[t] * T[g_col[t]];
-    S[e] = s;
+    if (act)
+        for (int t = g_ptr[e] + lane; t < g_ptr[e + 1]; t += 8) s += g_val[t] * T[g_col[t]];
+    s = group_sum<8>(s);
+    if (act && lane == 0) S[e] = s;
 }
 
 // Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction.
@@ -264,15 +270,28 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
         for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
     if (act) {
         const int t1 = adj_ptr[row + 1];
-        for (int t = adj_ptr[row]; t < t1; ++t) {
-            const double s = S[adj_e[t]];
-            const double *xq = X + (size_t)adj_col[t] * r;
+        // 4 neighbours per trip: their index, coefficient and row loads are all issued before the first
+        // use, which is what keeps enough bytes in flight for a latency-bound gather
+        for (int t = adj_ptr[row]; t < t1; t += 4) {
+            int qq[4];
+            double ss[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int j = (lane + c * LG) * W;
-                if (j < r) {
-                    if (V2) { const double2 v = *(const double2 *)(xq + j); acc[c][0] += s * v.x; acc[c][W - 1] += s * v.y; }
-                    else acc[c][0] += s * xq[j];
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u < t1 ? t + u : t1 - 1;
+                qq[u] = adj_col[tt];
+                ss[u] = t + u < t1 ? S[adj_e[tt]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double s = ss[u];
+                const double *xq = X + (size_t)qq[u] * r;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int j = (lane + c * LG) * W;
+                    if (j < r) {
+                        if (V2) { const double2 v = *(const double2 *)(xq + j); acc[c][0] += s * v.x; acc[c][W - 1] += s * v.y; }
+                        else acc[c][0] += s * xq[j];
+                    }
                 }
             }
         }
@@ -594,6 +613,8 @@ struct lorads_hip_ctx {
     long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
     double ms_samp = 0, ms_samp_spmm = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_mv, pend_sp;
+    std::vector<hipEvent_t> ev_pool; // pre-created (hipEventCreate is too slow for the timed region)
+    size_t ev_next = 0;
 };
 
 namespace {
@@ -726,7 +747,8 @@ int build_gram(Block &B, const lorads_hip_block &hb, const std::vector<int> &a_e
 int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     B.n = hb.n; B.r = hb.rank; B.nrow = hb.nrow; B.na = hb.a_ptr[hb.nrow]; B.nc = hb.c_nnz;
     if (B.r > 512) return fail_msg("rank > 512 is not supported by the row kernels");
-    if (nblocks_for((size_t)B.n, 4) > MAXPART) return fail_msg("cone dimension too large for the partial-sum slots of this build");
+    if (nblocks_for((size_t)B.n, TPB / lg_for(B.r)) > MAXPART)
+        return fail_msg("cone dimension too large for the partial-sum slots of this build");
     std::vector<std::pair<int, int>> posA(B.na), posU;
     for (int t = 0; t < B.na; ++t) {
         if (hb.a_row[t] < hb.a_col[t] || hb.a_col[t] < 0 || hb.a_row[t] >= hb.n) return fail_msg("A entry out of range / not lower-triangular");
@@ -886,19 +908,21 @@ void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, d
     pairdots(c, B.pa, X, Y, B.r, B.T, g);
     LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T, scale, cv, mode, B.row_idx, vec, g);
 }
-void sval(lorads_hip_ctx *c, const Pattern &P, bool with_c, int mode, const WArgs &wa, Guard g) {
-    if (P.ne == 0) return;
-    LAUNCH(k_sval, nblocks_for((size_t)P.ne, TPB), P.ne, P.e_ptr, P.e_con, P.e_val, with_c ? P.cbase : nullptr, mode, wa, P.S, g);
+void sval(lorads_hip_ctx *c, const Pattern &P, bool with_c, int mode, const WArgs &wa, Guard g, CGState *reset = nullptr,
+          int nreset = 0) {
+    if (P.ne == 0 && !reset) return;
+    LAUNCH(k_sval, std::max(1, nblocks_for((size_t)P.ne, TPB)), P.ne, P.e_ptr, P.e_con, P.e_val, with_c ? P.cbase : nullptr, mode,
+           wa, P.S, g, reset, nreset);
 }
 
 // one application of the CG operator  out = epilogue(x + (sum_i <A_i, sym(x V^T)> A_i) V)
 // (linSysProduct, lorads_admm.c:376-391); returns #partials in `part`
 int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x, int mode, const double *rhs, double *out,
                    double *part, Guard g) {
-    const bool samp = c->prof && (c->n_matvec % c->prof_every == 0);
+    const bool samp = c->prof && (c->n_matvec % c->prof_every == 0) && c->ev_next + 3 <= c->ev_pool.size();
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (samp) {
-        hipEventCreate(&e0); hipEventCreate(&e1);
+        e0 = c->ev_pool[c->ev_next++]; e1 = c->ev_pool[c->ev_next++];
         hipEventRecord(e0, c->stream);
     }
     int grid;
@@ -907,7 +931,7 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
     } else {
         pairdots(c, B.pa, x, V, B.r, B.T, g);
         if (B.has_gram) {
-            LAUNCH(k_sgram, nblocks_for((size_t)B.pa.ne, TPB), B.pa.ne, B.g_ptr, B.g_col, B.g_val, B.T, B.pa.S, g);
+            LAUNCH(k_sgram, nblocks_for((size_t)B.pa.ne, TPB / 8), B.pa.ne, B.g_ptr, B.g_col, B.g_val, B.T, B.pa.S, g);
         } else {
             LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T, 1.0, B.wtmp, (int)CV_SET,
                    B.row_idx, (double *)nullptr, g);
@@ -915,7 +939,7 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
             wa.w = B.wtmp;
             sval(c, B.pa, false, W_COMPACT, wa, g);
         }
-        if (samp) { hipEventCreate(&e2); hipEventRecord(e2, c->stream); }
+        if (samp) { e2 = c->ev_pool[c->ev_next++]; hipEventRecord(e2, c->stream); }
         grid = spmm(c, B, B.pa, V, mode, x, rhs, 0.0, out, part, g);
     }
     if (samp) {
@@ -938,11 +962,10 @@ void drain_events(lorads_hip_ctx *c) {
         float ms = 0;
         hipEventElapsedTime(&ms, pr.first, pr.second);
         c->ms_samp_spmm += ms; c->n_samp_spmm++;
-        hipEventDestroy(pr.first);
     }
-    for (auto &pr : c->pend_mv) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     c->pend_mv.clear();
     c->pend_sp.clear();
+    c->ev_next = 0;
 }
 
 // ---- one CG solve, split so that it can be enqueued speculatively and resumed
@@ -957,13 +980,13 @@ struct Solve {
 };
 
 // rhs = V - (C + sum_i M1_i A_i) V / rho, initial residual, state  (lorads_admm.c:432-463, lorads_cgs.c:115,149-172)
-void solve_front(lorads_hip_ctx *c, const Solve &s, double rho, double tol) {
+void solve_front(lorads_hip_ctx *c, const Solve &s, double rho, double tol, CGState *reset = nullptr, int nreset = 0) {
     Block &B = *s.B;
     double *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;
     double *pA = part_slot(c, 0), *pB = part_slot(c, 1);
     WArgs wa{};
     wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.cv = B.cv; wa.row_idx = B.row_idx; wa.rho = rho;
-    sval(c, B.pu, true, W_ADMM, wa, s.front);
+    sval(c, B.pu, true, W_ADMM, wa, s.front, reset, nreset);
     const int nb1 = spmm(c, B, B.pu, s.V, OP_RHS, nullptr, nullptr, rho, rhs, pB, s.front);
     const int na = apply_operator(c, B, s.V, s.x, OP_RES, rhs, r, pA, s.front);
     LAUNCH(k_cg_init, s.gv, s.len, s.st, pA, na, pB, nb1, tol, r, p, s.front);
@@ -1038,7 +1061,9 @@ void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, do
             if (resume_iter > 0) solve_iter_tail(c, s, resume_iter - 1, tol, maxit);
             solve_iters(c, s, resume_iter, std::min(resume_iter + more, maxit), tol, maxit);
         } else {
-            solve_front(c, s, rho, tol);
+            // a fresh sweep marks every later stage "not finished" in its very first kernel
+            const bool fresh0 = stg == 0 && resume_iter < 0 && 2 * c->nb - 1 <= TPB;
+            solve_front(c, s, rho, tol, fresh0 ? c->st + 1 : nullptr, fresh0 ? 2 * c->nb - 1 : 0);
             solve_iters(c, s, 0, std::min(B.spec[half], maxit), tol, maxit);
         }
         refresh_after_solve(c, B, &s.st->done);
@@ -1109,6 +1134,9 @@ int finish_sweep(lorads_hip_ctx *c, int *iters) {
 
 int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
     int first = 0, resume = -1;
+    // every stage starts "not finished": a stage whose predecessor misses its speculation must stay
+    // blocked (and block its successors) instead of seeing last iteration's done word
+    if (2 * c->nb - 1 > TPB) HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * (size_t)(2 * c->nb), c->stream));
     for (;;) {
         enqueue_sweep(c, first, resume, rho, tol, maxit);
         if (with_eval && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
@@ -1166,6 +1194,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
     drain_events(c);
+    for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &B : c->blk) {
         B.pa.release(); B.pu.release();
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.cv); hipFree(B.wtmp);
@@ -1442,6 +1471,10 @@ int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
     drain_events(c);
     c->prof = enable;
     c->prof_every = std::max(1, every);
+    if (enable && c->ev_pool.empty()) {
+        c->ev_pool.resize(3 * 1024);
+        for (auto &e : c->ev_pool) HC(hipEventCreate(&e));
+    }
     c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = c->n_resume = 0;
     c->ms_samp = c->ms_samp_spmm = 0;
     return 0;

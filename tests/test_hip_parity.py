@@ -217,12 +217,12 @@ def test_cg_long_solve_with_restarts(built):
             s.be.set_mat(host.MAT_V, 0, V)
             s.be.set_vec(host.VEC_LAMBDA, np.linspace(-1, 1, s.m))
             s.be.init_constr(host.PAIR_UV)
-        ia = hs.be.admm_update_var(0.3, 1e-13, 800)
-        ib = os_.be.admm_update_var(0.3, 1e-13, 800)
-        assert ib > 40, ib
-        assert abs(ia - ib) <= max(2, 0.05 * ib), (ia, ib)
+        ia = hs.be.admm_update_var(0.3, 1e-9, 800)
+        ib = os_.be.admm_update_var(0.3, 1e-9, 800)
+        assert 42 < ib < 1500, ib
+        assert abs(ia - ib) <= max(3, 0.05 * ib), (ia, ib)
         Ua, Ub = hs.be.get_mat(host.MAT_U, 0), os_.be.get_mat(host.MAT_U, 0)
-        assert np.allclose(Ua, Ub, rtol=0, atol=1e-7 * np.abs(Ub).max())
+        assert np.allclose(Ua, Ub, rtol=0, atol=1e-6 * np.abs(Ub).max())
     finally:
         hs.close()
         os_.close()
