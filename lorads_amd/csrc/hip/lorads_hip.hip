@@ -122,37 +122,51 @@ enum { DIR_BETA = 1, DIR_RESTART = 2 };
 enum { CV_SET = 0, CV_ADD = 1, CV_DELTA = 2 };
 
 // ------------------------------------------------------------------ kernels
-// pair dot of one pattern entry, LG lanes, 16-byte loads when r is even
-template <int LG, bool V2>
-__device__ __forceinline__ double pair_dot(const double *__restrict__ X, const double *__restrict__ Y, int p, int q, int r,
-                                           int lane) {
-    const double *xp = X + (size_t)p * r, *yq = Y + (size_t)q * r;
-    double s = 0.0;
-    if (V2) {
-        const double2 *xp2 = (const double2 *)xp, *yq2 = (const double2 *)yq;
-        const int h = r >> 1;
-        if (p == q) {
-            for (int j = lane; j < h; j += LG) { const double2 a = xp2[j], b = yq2[j]; s += a.x * b.x + a.y * b.y; }
-        } else {
-            const double2 *xq2 = (const double2 *)(X + (size_t)q * r), *yp2 = (const double2 *)(Y + (size_t)p * r);
-            for (int j = lane; j < h; j += LG) {
-                const double2 a = xp2[j], b = yq2[j], c = xq2[j], d = yp2[j];
-                s += (a.x * b.x + a.y * b.y) + (c.x * d.x + c.y * d.y);
+// Column slices: lane l of an LG-lane group owns columns (l + c*LG)*W .. +W-1 for c = 0..NS-1 (W = 2: one
+// 16-byte load per step).  NS is a compile-time constant and every load is UNCONDITIONAL (the address is
+// clamped into the row, the value masked afterwards): a per-element `if (j < r) load` makes hipcc branch
+// around each load and wait vmcnt(0) per element, which serialises the gather (cdna_hip_programming.md 5, trap c).
+template <int LG, bool V2, int NS>
+struct Slice {
+    static constexpr int W = V2 ? 2 : 1;
+    __device__ static __forceinline__ void load(const double *__restrict__ row, int r, int lane, double (&v)[NS][W]) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const int j = (lane + c * LG) * W;
+            const bool ok = j < r;
+            const int jc = ok ? j : 0;
+            if (V2) {
+                const double2 t = *(const double2 *)(row + jc);
+                v[c][0] = ok ? t.x : 0.0;
+                v[c][W - 1] = ok ? t.y : 0.0;
+            } else {
+                const double t = row[jc];
+                v[c][0] = ok ? t : 0.0;
             }
         }
-    } else {
-        if (p == q) {
-            for (int j = lane; j < r; j += LG) s += xp[j] * yq[j];
-        } else {
-            const double *xq = X + (size_t)q * r, *yp = Y + (size_t)p * r;
-            for (int j = lane; j < r; j += LG) s += xp[j] * yq[j] + xq[j] * yp[j];
-        }
     }
-    return s;
+};
+
+// pair dot of one pattern entry, LG lanes: x_p.y_q + x_q.y_p (p != q) or x_p.y_p; all row loads issued first
+template <int LG, bool V2, int NS>
+__device__ __forceinline__ double pair_dot(const double *__restrict__ X, const double *__restrict__ Y, int p, int q, int r,
+                                           int lane) {
+    constexpr int W = V2 ? 2 : 1;
+    double a[NS][W], b[NS][W], cc[NS][W], d[NS][W];
+    Slice<LG, V2, NS>::load(X + (size_t)p * r, r, lane, a);
+    Slice<LG, V2, NS>::load(Y + (size_t)q * r, r, lane, b);
+    Slice<LG, V2, NS>::load(X + (size_t)q * r, r, lane, cc);
+    Slice<LG, V2, NS>::load(Y + (size_t)p * r, r, lane, d);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int w = 0; w < W; ++w) { s1 += a[c][w] * b[c][w]; s2 += cc[c][w] * d[c][w]; }
+    return p == q ? s1 : s1 + s2;
 }
 
 // T_e = X_p.Y_q + X_q.Y_p  (p != q)   |   X_p.Y_p  (p == q); LG lanes share one pattern entry
-template <int LG, bool V2>
+template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
                                                   const double *__restrict__ X, const double *__restrict__ Y, int r,
                                                   double *__restrict__ T, Guard g) {
@@ -160,13 +174,13 @@ __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict_
     const int e = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = e < ne;
     const int p = act ? erow[e] : 0, q = act ? ecol[e] : 0;
-    double s = pair_dot<LG, V2>(X, Y, p, q, r, lane);
+    double s = pair_dot<LG, V2, NS>(X, Y, p, q, r, lane);
     s = group_sum<LG>(s);
     if (act && lane == 0) T[e] = s;
 }
 
 // partial of sum_e c_e * pairdot_e  (objective <C, sym(X Y^T)>); grid-stride so that the grid stays <= MAXPART
-template <int LG, bool V2>
+template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
                                              const double *__restrict__ cval, const double *__restrict__ X,
                                              const double *__restrict__ Y, int r, double *__restrict__ part, Guard g) {
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ ero
     const int lane = threadIdx.x % LG, per = TPB / LG;
     double s = 0.0; // every lane keeps its own slice; the block sum adds the slices
     for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per)
-        s += pair_dot<LG, V2>(X, Y, erow[e], ecol[e], r, lane) * cval[e];
+        s += pair_dot<LG, V2, NS>(X, Y, erow[e], ecol[e], r, lane) * cval[e];
     const double t = block_sum(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
@@ -251,8 +265,7 @@ __global__ __launch_bounds__(TPB) void k_sgram(int ne, const int *__restrict__ g
 }
 
 // Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction.
-// V2: every lane owns column pairs (16-byte loads), r even.
-template <int LG, bool V2>
+template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj_ptr, const int *__restrict__ adj_col,
                                               const int *__restrict__ adj_e, const double *__restrict__ S,
                                               const double *__restrict__ X, int r, int mode, const double *__restrict__ xin,
@@ -260,100 +273,101 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
                                               double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
     if (blocked(g)) return;
+    constexpr int W = V2 ? 2 : 1;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
-    constexpr int W = V2 ? 2 : 1;   // columns per lane per step
-    double acc[8][W];
+    const int rowc = act ? row : 0;
+    double acc[NS][W];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < NS; ++c)
 #pragma unroll
         for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
-    if (act) {
-        const int t1 = adj_ptr[row + 1];
-        // 4 neighbours per trip: their index, coefficient and row loads are all issued before the first
-        // use, which is what keeps enough bytes in flight for a latency-bound gather
-        for (int t = adj_ptr[row]; t < t1; t += 4) {
-            int qq[4];
-            double ss[4];
+    const int t0 = adj_ptr[rowc], t1 = act ? adj_ptr[rowc + 1] : t0;
+    // 2 neighbours per trip: index, coefficient and row loads of both are issued before the first use
+    for (int t = t0; t < t1; t += 2) {
+        const bool two = t + 1 < t1;
+        const int ta = t, tb = two ? t + 1 : t;
+        const int qa = adj_col[ta], qb = adj_col[tb];
+        const double sa = S[adj_e[ta]], sb0 = S[adj_e[tb]];
+        double va[NS][W], vb[NS][W];
+        Slice<LG, V2, NS>::load(X + (size_t)qa * r, r, lane, va);
+        Slice<LG, V2, NS>::load(X + (size_t)qb * r, r, lane, vb);
+        const double sb = two ? sb0 : 0.0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int tt = t + u < t1 ? t + u : t1 - 1;
-                qq[u] = adj_col[tt];
-                ss[u] = t + u < t1 ? S[adj_e[tt]] : 0.0;
-            }
+        for (int c = 0; c < NS; ++c)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double s = ss[u];
-                const double *xq = X + (size_t)qq[u] * r;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int j = (lane + c * LG) * W;
-                    if (j < r) {
-                        if (V2) { const double2 v = *(const double2 *)(xq + j); acc[c][0] += s * v.x; acc[c][W - 1] += s * v.y; }
-                        else acc[c][0] += s * xq[j];
-                    }
-                }
-            }
-        }
+            for (int w = 0; w < W; ++w) acc[c][w] += sa * va[c][w] + sb * vb[c][w];
     }
     double local = 0.0;
-    if (act) {
+    {
+        double xi[NS][W], rh[NS][W];
+        const size_t base = (size_t)rowc * r;
+        if (mode == OP_CG || mode == OP_RES) Slice<LG, V2, NS>::load(xin + base, r, lane, xi);
+        if (mode == OP_RES) Slice<LG, V2, NS>::load(rhs + base, r, lane, rh);
+        if (mode == OP_RHS) Slice<LG, V2, NS>::load(X + base, r, lane, xi);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NS; ++c) {
             const int j0 = (lane + c * LG) * W;
+            double v[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                const int j = j0 + w;
-                if (j < r) {
-                    const size_t idx = (size_t)row * r + j;
-                    const double a = acc[c][w];
-                    double v;
-                    if (mode == OP_CG) { const double xi = xin[idx]; v = xi + a; local += xi * v; }
-                    else if (mode == OP_RES) { v = rhs[idx] - (xin[idx] + a); local += v * v; }
-                    else if (mode == OP_RHS) { v = X[idx] - a / rho; local += fabs(v); }
-                    else { v = 2.0 * a; local += v * v; }
-                    out[idx] = v;
-                }
+                const double a = acc[c][w];
+                if (mode == OP_CG) { v[w] = xi[c][w] + a; local += xi[c][w] * v[w]; }
+                else if (mode == OP_RES) { v[w] = rh[c][w] - (xi[c][w] + a); local += v[w] * v[w]; }
+                else if (mode == OP_RHS) { v[w] = xi[c][w] - a / rho; local += fabs(v[w]); }
+                else { v[w] = 2.0 * a; local += v[w] * v[w]; }
+            }
+            if (act && j0 < r) {
+                if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
+                else out[base + j0] = v[0];
             }
         }
     }
-    const double t = block_sum(local, sh);
+    const double t = block_sum(act ? local : 0.0, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
 // Max-Cut-type cones (every A_i = a_i e_p e_p^T): the whole operator is row-local,
 //   out_p = x_p + g_p (x_p . V_p) V_p,  g_p = sum_i a_i^2  -> one pass over x and V
-template <int LG>
+template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict__ gd, const double *__restrict__ V, int r,
                                                  int mode, const double *__restrict__ xin, const double *__restrict__ rhs,
                                                  double *__restrict__ out, double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
     if (blocked(g)) return;
+    constexpr int W = V2 ? 2 : 1;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
-    double xv[8], vv[8], d = 0.0;
+    const int rowc = act ? row : 0;
+    const size_t base = (size_t)rowc * r;
+    double xv[NS][W], vv[NS][W], rh[NS][W];
+    Slice<LG, V2, NS>::load(xin + base, r, lane, xv);
+    Slice<LG, V2, NS>::load(V + base, r, lane, vv);
+    if (mode == OP_RES) Slice<LG, V2, NS>::load(rhs + base, r, lane, rh);
+    const double gr = gd[rowc];
+    double d = 0.0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int j = lane + c * LG;
-        const bool ok = act && j < r;
-        xv[c] = ok ? xin[(size_t)row * r + j] : 0.0;
-        vv[c] = ok ? V[(size_t)row * r + j] : 0.0;
-        d += xv[c] * vv[c];
-    }
-    d = group_sum<LG>(d) * (act ? gd[row] : 0.0);
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int w = 0; w < W; ++w) d += xv[c][w] * vv[c][w];
+    d = group_sum<LG>(d) * gr;
     double local = 0.0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int j = lane + c * LG;
-        if (act && j < r) {
-            const size_t idx = (size_t)row * r + j;
-            double v = xv[c] + d * vv[c];
-            if (mode == OP_CG) local += xv[c] * v;
-            else { v = rhs[idx] - v; local += v * v; }
-            out[idx] = v;
+    for (int c = 0; c < NS; ++c) {
+        const int j0 = (lane + c * LG) * W;
+        double v[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            v[w] = xv[c][w] + d * vv[c][w];
+            if (mode == OP_CG) local += xv[c][w] * v[w];
+            else { v[w] = rh[c][w] - v[w]; local += v[w] * v[w]; }
+        }
+        if (act && j0 < r) {
+            if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
+            else out[base + j0] = v[0];
         }
     }
-    const double t = block_sum(local, sh);
+    const double t = block_sum(act ? local : 0.0, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
@@ -863,41 +877,64 @@ int allreduce_dev(lorads_hip_ctx *c, double *buf, int count) {
 // ---- launch helpers
 #define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, c->stream, __VA_ARGS__)
 
+// (LG, V2, NS) for a rank: 8 lanes x 16-byte loads when r is even and <= 128, else 8/32/64 lanes x 8-byte loads
+struct Shape {
+    int lg, v2, ns;
+};
+inline Shape shape_for(int r) {
+    Shape s;
+    s.v2 = use_v2(r);
+    s.lg = lg_for(r);
+    const int w = s.v2 ? 2 : 1;
+    s.ns = (r + s.lg * w - 1) / (s.lg * w);
+    return s;
+}
+#define NS_SWITCH(LGV, V2V, ns, ...)                                     \
+    switch (ns) {                                                        \
+    case 1: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 3; __VA_ARGS__; } break; \
+    case 4: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 4; __VA_ARGS__; } break; \
+    case 5: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 5; __VA_ARGS__; } break; \
+    case 6: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 6; __VA_ARGS__; } break; \
+    case 7: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 7; __VA_ARGS__; } break; \
+    default: { constexpr int LG_ = LGV; constexpr bool V2_ = V2V; constexpr int NS_ = 8; __VA_ARGS__; } break; \
+    }
+#define SHAPE_DISPATCH(sh, ...)                                   \
+    do {                                                          \
+        if ((sh).v2) { NS_SWITCH(8, true, (sh).ns, __VA_ARGS__) }        \
+        else if ((sh).lg == 8) { NS_SWITCH(8, false, (sh).ns, __VA_ARGS__) } \
+        else if ((sh).lg == 32) { NS_SWITCH(32, false, (sh).ns, __VA_ARGS__) } \
+        else { NS_SWITCH(64, false, (sh).ns, __VA_ARGS__) }              \
+    } while (0)
+
 void pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double *Y, int r, double *T, Guard g) {
     if (P.ne == 0) return;
-    const int lg = lg_for(r), grid = nblocks_for((size_t)P.ne, TPB / lg);
-    if (use_v2(r)) LAUNCH((k_pairdots<8, true>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
-    else if (lg == 8) LAUNCH((k_pairdots<8, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
-    else if (lg == 32) LAUNCH((k_pairdots<32, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
-    else LAUNCH((k_pairdots<64, false>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g);
+    const Shape sh = shape_for(r);
+    const int grid = nblocks_for((size_t)P.ne, TPB / sh.lg);
+    SHAPE_DISPATCH(sh, LAUNCH((k_pairdots<LG_, V2_, NS_>), grid, P.ne, P.erow, P.ecol, X, Y, r, T, g));
 }
 // returns the number of partials written
 int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin, const double *rhs,
          double rho, double *out, double *part, Guard g) {
-    const int lg = lg_for(B.r), grid = nblocks_for((size_t)B.n, TPB / lg);
-#define SPMM_ARGS B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin, rhs, rho, out, part, g
-    if (use_v2(B.r)) LAUNCH((k_spmm<8, true>), grid, SPMM_ARGS);
-    else if (lg == 8) LAUNCH((k_spmm<8, false>), grid, SPMM_ARGS);
-    else if (lg == 32) LAUNCH((k_spmm<32, false>), grid, SPMM_ARGS);
-    else LAUNCH((k_spmm<64, false>), grid, SPMM_ARGS);
-#undef SPMM_ARGS
+    const Shape sh = shape_for(B.r);
+    const int grid = nblocks_for((size_t)B.n, TPB / sh.lg);
+    SHAPE_DISPATCH(sh, LAUNCH((k_spmm<LG_, V2_, NS_>), grid, B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin, rhs, rho,
+                              out, part, g));
     return grid;
 }
 int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs, double *out,
             double *part, Guard g) {
-    const int lg = B.r <= 64 ? 8 : (B.r <= 256 ? 32 : 64), grid = nblocks_for((size_t)B.n, TPB / lg);
-    if (lg == 8) LAUNCH(k_op_diag<8>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
-    else if (lg == 32) LAUNCH(k_op_diag<32>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
-    else LAUNCH(k_op_diag<64>, grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g);
+    const Shape sh = shape_for(B.r);
+    const int grid = nblocks_for((size_t)B.n, TPB / sh.lg);
+    SHAPE_DISPATCH(sh, LAUNCH((k_op_diag<LG_, V2_, NS_>), grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g));
     return grid;
 }
 int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part, Guard g) {
     if (B.nc == 0) return 0;
-    const int lg = lg_for(B.r), grid = std::min(nblocks_for((size_t)B.nc, TPB / lg), 1024);
-    if (use_v2(B.r)) LAUNCH((k_obj<8, true>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
-    else if (lg == 8) LAUNCH((k_obj<8, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
-    else if (lg == 32) LAUNCH((k_obj<32, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
-    else LAUNCH((k_obj<64, false>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g);
+    const Shape sh = shape_for(B.r);
+    const int grid = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
+    SHAPE_DISPATCH(sh, LAUNCH((k_obj<LG_, V2_, NS_>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g));
     return grid;
 }
 
