@@ -66,8 +66,11 @@ def replicate_blocks(path, nblk, out):
     return out
 
 
-def admm_steps(be, host, rho, err1, steps):
-    """`steps` ADMM iterations through the operator table; returns (err1, cg_iters, pobj, dobj)."""
+def admm_steps(be, host, rho, err1, steps, session=None):
+    """`steps` ADMM iterations through the operator table; returns (err1, cg_iters, pobj, dobj).
+    With a session the loop itself runs in the C host (lrd_session_admm_steps), as it does in a solve."""
+    if session is not None:
+        return session.admm_steps(steps, rho, err1)
     cg = 0
     pobj = dobj = 0.0
     fused = be.has_admm_step
@@ -234,14 +237,14 @@ def main():
         err1_start = err1
 
     # ---- warm-up, then exactly K timed steps
-    err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup)
+    err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup, s)
     s.hip_profile(1, a.sample_every)
     s.hip_sync()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    err1, cg_iters, pobj, dobj = admm_steps(be, host, rho, err1, a.steps)
+    err1, cg_iters, pobj, dobj = admm_steps(be, host, rho, err1, a.steps, s)
     s.hip_sync()
     torch.cuda.synchronize()
     if dist:

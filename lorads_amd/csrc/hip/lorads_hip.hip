@@ -613,6 +613,7 @@ struct lorads_hip_ctx {
     double *Dtmp = nullptr;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
     double *part = nullptr;   // NSLOT x MAXPART partial sums
+    char *ctrl = nullptr, *h_ctrl = nullptr; // [64 scalars | CG states] device + pinned mirror: ONE readback copy
     double *scal = nullptr;   // 64 device scalars
     CGState *st = nullptr;    // one per (cone, half)
     CGState *h_st = nullptr;  // pinned mirror
@@ -1065,8 +1066,8 @@ void refresh_after_solve(lorads_hip_ctx *c, Block &B, const int *need) {
 }
 
 int read_states(lorads_hip_ctx *c) {
-    HC(hipMemcpyAsync(c->h_st, c->st, sizeof(CGState) * (size_t)(2 * c->nb), hipMemcpyDeviceToHost, c->stream));
-    HC(hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
+    HC(hipMemcpyAsync(c->h_ctrl, c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)(2 * c->nb), hipMemcpyDeviceToHost,
+                      c->stream));
     HC(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1121,12 +1122,13 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need) {
     if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, g);
     const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
     if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
-    LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
+    bool first_obj = true;
     for (auto &B : c->blk) {
         constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
-        if (go) LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, 1, c->scal + 2, g);
+        if (go) { LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, first_obj ? 0 : 1, c->scal + 2, g); first_obj = false; }
     }
+    if (first_obj) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
     if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part] per evaluation
         HC(hipMemcpyAsync(c->csum + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
@@ -1209,13 +1211,17 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
-        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) || dalloc(&c->scal, 64) ||
-        dalloc(&c->st, (size_t)2 * c->nb) || dalloc(&c->ring_ab, (size_t)2 * c->L)) {
+        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
+        dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
+        dalloc(&c->ring_ab, (size_t)2 * c->L)) {
         lorads_hip_destroy(c);
         return 1;
     }
-    HC(hipHostMalloc((void **)&c->h_st, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
-    HC(hipHostMalloc((void **)&c->h_scal, sizeof(double) * 64));
+    HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
+    c->scal = (double *)c->ctrl;
+    c->st = (CGState *)(c->ctrl + 64 * sizeof(double));
+    c->h_scal = (double *)c->h_ctrl;
+    c->h_st = (CGState *)(c->h_ctrl + 64 * sizeof(double));
     HC(hipMemset(c->lambda, 0, sizeof(double) * (size_t)std::max(c->m, 1)));
     HC(hipMemset(c->csum, 0, sizeof(double) * (size_t)(c->m + 2)));
     HC(hipMemset(c->q12, 0, sizeof(double) * (size_t)(2 * c->m + 2)));
@@ -1239,10 +1245,9 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         hipFree(B.g_val);
     }
     free_factors(c);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->scal); hipFree(c->st);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl);
     hipFree(c->ring_ab);
-    if (c->h_st) hipHostFree(c->h_st);
-    if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -132,6 +132,34 @@ int lrd_session_admm(lrd_session *s, int iter_ceiling) {
     return lrd_admm_optimize(&s->par, &s->sol, 0, iter_ceiling, lrd_time());
 }
 
+/* `steps` ADMM iterations at fixed rho with the CG tolerance min(1e-2 err1, 1e-8) refreshed every
+ * iteration (the measured step of bench.py; one iteration = lorads_admm.c:76-81 + :120).
+ * io = {err1 (in/out), cg iterations (out), pobj (out), dobj (out)} */
+int lrd_session_admm_steps(lrd_session *s, int steps, double rho, double io[4]) {
+    if (!s->have_be) return 1;
+    lrd_backend *be = &s->be;
+    double err1 = io[0], pobj = 0, dobj = 0;
+    long cg = 0;
+    for (int it = 0; it < steps; ++it) {
+        double tol = err1 * 1e-2 < 1e-8 ? err1 * 1e-2 : 1e-8;
+        if (be->admm_step && s->sol.use_fused_step) {
+            double o[4];
+            if (be->admm_step(be->ctx, rho, tol, 800, o)) return 1;
+            cg += (long)o[0]; pobj = o[1]; dobj = o[2]; err1 = o[3];
+        } else {
+            int c = 0;
+            if (be->admm_update_var(be->ctx, rho, tol, 800, &c)) return 1;
+            cg += c;
+            be->cal_obj(be->ctx, LRD_PAIR_UV, &pobj);
+            be->cal_dual_obj(be->ctx, &dobj);
+            be->update_dimacs(be->ctx, LRD_PAIR_UV, &err1);
+        }
+        be->update_dual_var(be->ctx, rho);
+    }
+    io[0] = err1; io[1] = (double)cg; io[2] = pobj; io[3] = dobj;
+    return 0;
+}
+
 /* results: [pObj, dObj, constrVio(1), pdGap, alm_outer, alm_inner, alm_rho, admm_iter, cg_iter, admm_rho,
  *           t_alm, t_admm, status, admm_iters_first, cg_iters_first, constrVio(Inf)] */
 int lrd_session_results(lrd_session *s, double out[16]) {

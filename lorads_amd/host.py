@@ -363,6 +363,13 @@ class Session:
     def admm(self, iter_ceiling):
         return self.lib.lrd_session_admm(self.h, iter_ceiling)
 
+    def admm_steps(self, steps, rho, err1):
+        """`steps` ADMM iterations in the C host loop (no per-iteration Python); returns (err1, cg, pobj, dobj)"""
+        io = (C.c_double * 4)(err1, 0.0, 0.0, 0.0)
+        self.lib.lrd_session_admm_steps.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp]
+        _check(self.lib.lrd_session_admm_steps(self.h, int(steps), float(rho), io), "admm_steps")
+        return io[0], int(io[1]), io[2], io[3]
+
     def results(self):
         out = (C.c_double * 16)()
         _check(self.lib.lrd_session_results(self.h, out), "results")
