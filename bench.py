@@ -184,13 +184,17 @@ def main():
     if a.gpus != world and world > 1:
         log("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     dist = None
+    # rehearsal knobs (1-GPU box): LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 run N ranks on one card
+    backend = os.environ.get("LORADS_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     if rank == 0:
         __graft_entry__.build()
     if dist:
