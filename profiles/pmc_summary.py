@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
+prescribes) of bench.py into per-kernel HBM-side traffic per launch for the ADMM part of the run.
+
+Corrections applied (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact.  Infinity-Cache hits are
+counted by these fabric-side counters, so "traffic" is L2-miss traffic, an upper bound of HBM bytes.
+
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <workload>
+"""
+import collections
+import csv
+import json
+import re
+import statistics
+import sys
+
+
+def short(n):
+    m = re.search(r"(k_\w+|__amd_\w+)", n)
+    return m.group(1) if m else n[:40]
+
+
+def per_kernel(path, counter):
+    rows = list(csv.DictReader(open(path)))
+    last = max(i for i, r in enumerate(rows) if "k_his_two" in r["Kernel_Name"])
+    agg = collections.defaultdict(list)
+    for r in rows[last + 1:]:
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"workload": sys.argv[4], "unit": "bytes per launch", "corrections": "KiB->bytes; FETCH_SIZE x2 (gfx950); WRITE_SIZE x1",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    f = fetch.get(k, [0.0])
+    w = write.get(k, [0.0])
+    out["kernels"][k] = {"launches": len(f), "read_bytes_mean": 2 * 1024 * sum(f) / len(f), "read_bytes_median": 2 * 1024 * statistics.median(f),
+                         "write_bytes_mean": 1024 * sum(w) / len(w)}
+ks = out["kernels"]
+if "k_op_diag" in ks:
+    op = ks["k_op_diag"]["read_bytes_median"] + ks["k_op_diag"]["write_bytes_mean"]
+    out["cg_operator_application"] = {"kernels": ["k_op_diag"], "traffic_bytes": op}
+elif "k_spmm" in ks:
+    # the CG operator uses the A-pattern adjacency (the smaller of the two k_spmm populations -> median)
+    op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_pairdots", "k_sgram", "k_spmm") if k in ks)
+    out["cg_operator_application"] = {"kernels": [k for k in ("k_pairdots", "k_sgram", "k_spmm") if k in ks], "traffic_bytes": op}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["cg_operator_application"]))
