@@ -283,44 +283,54 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
 #pragma unroll
         for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
     const int t0 = adj_ptr[rowc], t1 = act ? adj_ptr[rowc + 1] : t0;
-    // 2 neighbours per trip: index, coefficient and row loads of both are issued before the first use
-    for (int t = t0; t < t1; t += 2) {
-        const bool two = t + 1 < t1;
-        const int ta = t, tb = two ? t + 1 : t;
-        const int qa = adj_col[ta], qb = adj_col[tb];
-        const double sa = S[adj_e[ta]], sb0 = S[adj_e[tb]];
-        double va[NS][W], vb[NS][W];
-        Slice<LG, V2, NS>::load(X + (size_t)qa * r, r, lane, va);
-        Slice<LG, V2, NS>::load(X + (size_t)qb * r, r, lane, vb);
-        const double sb = two ? sb0 : 0.0;
+    // epilogue operands are fetched up front: the kernel is bound by its chain of dependent loads
+    // (row pointer -> neighbour index -> coefficient / neighbour row), not by bandwidth
+    const size_t base = (size_t)rowc * r;
+    double xi[NS][W], rh[NS][W];
+    if (mode == OP_CG || mode == OP_RES) Slice<LG, V2, NS>::load(xin + base, r, lane, xi);
+    if (mode == OP_RES) Slice<LG, V2, NS>::load(rhs + base, r, lane, rh);
+    if (mode == OP_RHS) Slice<LG, V2, NS>::load(X + base, r, lane, xi);
+    // 4 neighbours per trip: the 8 index loads, then the 4 coefficient and 4 row gathers are all issued
+    // before the first use (out-of-range slots repeat the last neighbour with coefficient 0)
+    for (int t = t0; t < t1; t += 4) {
+        int q[4], e[4];
 #pragma unroll
-        for (int c = 0; c < NS; ++c)
+        for (int u = 0; u < 4; ++u) {
+            const int tt = t + u < t1 ? t + u : t1 - 1;
+            q[u] = adj_col[tt];
+            e[u] = adj_e[tt];
+        }
+        double sc[4], v[4][NS][W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) acc[c][w] += sa * va[c][w] + sb * vb[c][w];
+        for (int u = 0; u < 4; ++u) {
+            sc[u] = S[e[u]];
+            Slice<LG, V2, NS>::load(X + (size_t)q[u] * r, r, lane, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double su = t + u < t1 ? sc[u] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NS; ++c)
+#pragma unroll
+                for (int w = 0; w < W; ++w) acc[c][w] += su * v[u][c][w];
+        }
     }
     double local = 0.0;
-    {
-        double xi[NS][W], rh[NS][W];
-        const size_t base = (size_t)rowc * r;
-        if (mode == OP_CG || mode == OP_RES) Slice<LG, V2, NS>::load(xin + base, r, lane, xi);
-        if (mode == OP_RES) Slice<LG, V2, NS>::load(rhs + base, r, lane, rh);
-        if (mode == OP_RHS) Slice<LG, V2, NS>::load(X + base, r, lane, xi);
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-            const int j0 = (lane + c * LG) * W;
-            double v[W];
+    for (int c = 0; c < NS; ++c) {
+        const int j0 = (lane + c * LG) * W;
+        double v[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const double a = acc[c][w];
-                if (mode == OP_CG) { v[w] = xi[c][w] + a; local += xi[c][w] * v[w]; }
-                else if (mode == OP_RES) { v[w] = rh[c][w] - (xi[c][w] + a); local += v[w] * v[w]; }
-                else if (mode == OP_RHS) { v[w] = xi[c][w] - a / rho; local += fabs(v[w]); }
-                else { v[w] = 2.0 * a; local += v[w] * v[w]; }
-            }
-            if (act && j0 < r) {
-                if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
-                else out[base + j0] = v[0];
-            }
+        for (int w = 0; w < W; ++w) {
+            const double a = acc[c][w];
+            if (mode == OP_CG) { v[w] = xi[c][w] + a; local += xi[c][w] * v[w]; }
+            else if (mode == OP_RES) { v[w] = rh[c][w] - (xi[c][w] + a); local += v[w] * v[w]; }
+            else if (mode == OP_RHS) { v[w] = xi[c][w] - a / rho; local += fabs(v[w]); }
+            else { v[w] = 2.0 * a; local += v[w] * v[w]; }
+        }
+        if (act && j0 < r) {
+            if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
+            else out[base + j0] = v[0];
         }
     }
     const double t = block_sum(act ? local : 0.0, sh);
