@@ -32,6 +32,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def traffic_from_profiles(workload):
+    """HBM-side bytes per CG operator application from the committed PMC passes (profiles/, collected with
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; see profiles/pmc_summary.py)"""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc_%s.json" % workload):
+            best = os.path.join(pdir, f)
+    if not best:
+        return None, None
+    with open(best) as fh:
+        d = json.load(fh)
+    return d.get("cg_operator_application", {}).get("traffic_bytes"), os.path.relpath(best, ROOT)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -164,50 +179,14 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
                       "plain-C restatement (oracle/) on 1 host core" % (its, cg)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="rand20000", help="rand20000 (headline, cfg3b) | maxcut20000 (cfg3a) | any NAMED")
-    ap.add_argument("--times-log-rank", type=float, default=4.0)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--sample-every", type=int, default=4)
-    a = ap.parse_args()
-
-    import torch
-    import __graft_entry__
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
-    dist = None
-    # rehearsal knobs (1-GPU box): LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 run N ranks on one card
-    backend = os.environ.get("LORADS_DIST_BACKEND", "nccl")
-    dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-    if rank == 0:
-        __graft_entry__.build()
+def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
+    base = build_instance(workload, "/tmp/lorads_bench_%s.dat-s" % workload) if rank == 0 else None
     if dist:
         dist.barrier()
-    from lorads_amd import host
-
-    base = build_instance(a.workload, "/tmp/lorads_bench_%s.dat-s" % a.workload) if rank == 0 else None
-    if dist:
-        dist.barrier()
-    base = "/tmp/lorads_bench_%s.dat-s" % a.workload
+    base = "/tmp/lorads_bench_%s.dat-s" % workload
     path = base
     if world > 1:
-        path = "/tmp/lorads_bench_%s_x%d.dat-s" % (a.workload, world)
+        path = "/tmp/lorads_bench_%s_x%d.dat-s" % (workload, world)
         if rank == 0:
             replicate_blocks(base, world, path)
         dist.barrier()
@@ -232,7 +211,7 @@ def main():
     log("rank %d: phase 1 took %.2fs (%d inner its), rho=%.4g err1=%.3e n=%d r=%d" %
         (rank, time.time() - t0, int(res["alm_inner"]), rho, err1, info["n"], info["rank"]))
     state_file = "/tmp/lorads_bench_state_%d.bin" % os.getpid()
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and world == 1 and with_cpu:
         U, V = be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0)
         with open(state_file, "wb") as f:
             f.write(np.asfortranarray(U).tobytes(order="F"))
@@ -279,7 +258,7 @@ def main():
             "cg_iters_per_s": cg_iters / elapsed,
             "cg_iters_per_admm_iter": cg_iters / (world * a.steps),
             "config": {"workload": "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
-                                   % (a.workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]),
+                                   % (workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]),
                        "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": world,
                        "parallelism": "block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration" if world > 1 else "single GPU",
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (a.times_log_rank, rho)},
@@ -291,9 +270,10 @@ def main():
                          "launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"]),
                          "cg_iter_bytes": b_cg,
                          "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
-                         "traffic": None},
+                         "traffic": traffic_from_profiles(workload)[0],
+                         "traffic_source": traffic_from_profiles(workload)[1]},
         }
-        if world == 1 and not a.no_cpu:
+        if world == 1 and with_cpu:
             try:
                 cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)
                 cb["host_cores_total"] = os.cpu_count()
@@ -308,6 +288,55 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 0, "kind": "reference",
                                    "sample": "timed at N=1 only"}
     s.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rand20000", help="rand20000 (headline, cfg3b) | maxcut20000 (cfg3a) | any NAMED")
+    ap.add_argument("--times-log-rank", type=float, default=4.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Max-Cut n=20000 companion run")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--sample-every", type=int, default=4)
+    a = ap.parse_args()
+
+    import torch
+    import __graft_entry__
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    dist = None
+    # rehearsal knobs (1-GPU box): LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 run N ranks on one card
+    backend = os.environ.get("LORADS_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    if rank == 0:
+        __graft_entry__.build()
+    if dist:
+        dist.barrier()
+    from lorads_amd import host
+
+    out = run_workload(a, a.workload, torch, dist, device, world, rank, host, not a.no_cpu)
+    if rank == 0 and world == 1 and a.workload == "rand20000" and not a.no_extra:
+        # the north-star target sentence is phrased on Max-Cut n = 20000, r = 40 (cfg3a): reported beside the headline
+        ex = run_workload(a, "maxcut20000", torch, dist, device, world, rank, host, not a.no_cpu)
+        out["extra"] = [{k: ex[k] for k in ("value", "unit", "ms_per_step", "cg_iters_per_s", "cg_iters_per_admm_iter", "config",
+                                              "roofline", "cpu_baseline", "state") if k in ex}]
+        if "speedup_vs_cpu_1core" in ex:
+            out["extra"][0]["speedup_vs_cpu_1core"] = ex["speedup_vs_cpu_1core"]
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -114,6 +114,10 @@ struct Guard {
     const int *need;
 };
 __device__ __forceinline__ bool blocked(const Guard &g) { return (g.skip && *g.skip != 0) || (g.need && *g.need == 0); }
+// The gate words were written by the previous kernel, so reading them costs a cache-missing scalar load
+// (~1.5 us when it heads the kernel).  Kernels therefore evaluate `live` first but only USE it to predicate
+// their stores: the gate loads fly together with the kernel's own first loads.  A blocked kernel computes on
+// whatever is there and writes nothing.
 
 enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2 };
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
@@ -170,13 +174,13 @@ template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
                                                   const double *__restrict__ X, const double *__restrict__ Y, int r,
                                                   double *__restrict__ T, Guard g) {
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const int e = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = e < ne;
     const int p = act ? erow[e] : 0, q = act ? ecol[e] : 0;
     double s = pair_dot<LG, V2, NS>(X, Y, p, q, r, lane);
     s = group_sum<LG>(s);
-    if (act && lane == 0) T[e] = s;
+    if (live && act && lane == 0) T[e] = s;
 }
 
 // partial of sum_e c_e * pairdot_e  (objective <C, sym(X Y^T)>); grid-stride so that the grid stays <= MAXPART
@@ -185,13 +189,13 @@ __global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ ero
                                              const double *__restrict__ cval, const double *__restrict__ X,
                                              const double *__restrict__ Y, int r, double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const int lane = threadIdx.x % LG, per = TPB / LG;
     double s = 0.0; // every lane keeps its own slice; the block sum adds the slices
     for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per)
         s += pair_dot<LG, V2, NS>(X, Y, erow[e], ecol[e], r, lane) * cval[e];
     const double t = block_sum(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (live && threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
 // w_i = sum_k a_k T[e_k]; 8 lanes per constraint.  `mode` says what happens to the running
@@ -202,14 +206,14 @@ __global__ __launch_bounds__(TPB) void k_cv(int nrow, const int *__restrict__ a_
                                             const double *__restrict__ a_val, const double *__restrict__ T, double scale,
                                             double *__restrict__ cv, int mode, const int *__restrict__ row_idx,
                                             double *__restrict__ vec, Guard g) {
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const int i = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
     const bool act = i < nrow;
     double s = 0.0;
     if (act)
         for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) s += a_val[t] * T[a_e[t]];
     s = group_sum<8>(s);
-    if (act && lane == 0) {
+    if (live && act && lane == 0) {
         if (vec) {
             const int gi = row_idx[i];
             if (mode == CV_SET) vec[gi] = s * scale;
@@ -242,26 +246,26 @@ __global__ __launch_bounds__(TPB) void k_sval(int ne, const int *__restrict__ e_
     // first kernel of a sweep: mark every later stage "not finished" (stage 0 itself is reset by its k_cg_init,
     // nothing before that reads it)
     if (reset && blockIdx.x == 0 && threadIdx.x < nreset) reset[threadIdx.x].done = 0;
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const int e = blockIdx.x * TPB + threadIdx.x;
     if (e >= ne) return;
     double s = cbase ? cbase[e] : 0.0;
     for (int t = e_ptr[e]; t < e_ptr[e + 1]; ++t) s += weight_of(mode, wa, e_con[t]) * e_val[t];
-    S[e] = s;
+    if (live) S[e] = s;
 }
 // S = G T with G = A A^T over pattern entries (w = A T and S = A^T w in one pass); 8 lanes per entry so
 // that the dependent (index -> T) loads of one Gram row are in flight together
 __global__ __launch_bounds__(TPB) void k_sgram(int ne, const int *__restrict__ g_ptr, const int *__restrict__ g_col,
                                                const double *__restrict__ g_val, const double *__restrict__ T,
                                                double *__restrict__ S, Guard g) {
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const int e = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
     const bool act = e < ne;
     double s = 0.0;
     if (act)
         for (int t = g_ptr[e] + lane; t < g_ptr[e + 1]; t += 8) s += g_val[t] * T[g_col[t]];
     s = group_sum<8>(s);
-    if (act && lane == 0) S[e] = s;
+    if (live && act && lane == 0) S[e] = s;
 }
 
 // Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction.
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
                                               const double *__restrict__ rhs, double rho, double *__restrict__ out,
                                               double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     constexpr int W = V2 ? 2 : 1;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
@@ -328,13 +332,13 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
             else if (mode == OP_RHS) { v[w] = xi[c][w] - a / rho; local += fabs(v[w]); }
             else { v[w] = 2.0 * a; local += v[w] * v[w]; }
         }
-        if (act && j0 < r) {
+        if (live && act && j0 < r) {
             if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
             else out[base + j0] = v[0];
         }
     }
     const double t = block_sum(act ? local : 0.0, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (live && threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
 // Max-Cut-type cones (every A_i = a_i e_p e_p^T): the whole operator is row-local,
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
                                                  int mode, const double *__restrict__ xin, const double *__restrict__ rhs,
                                                  double *__restrict__ out, double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     constexpr int W = V2 ? 2 : 1;
     const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
     const bool act = row < n;
@@ -372,45 +376,45 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
             if (mode == OP_CG) local += xv[c][w] * v[w];
             else { v[w] = rh[c][w] - v[w]; local += v[w] * v[w]; }
         }
-        if (act && j0 < r) {
+        if (live && act && j0 < r) {
             if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
             else out[base + j0] = v[0];
         }
     }
     const double t = block_sum(act ? local : 0.0, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (live && threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
 // start of CGSolve (lorads_cgs.c:115,149-172): ||b||_1 and the initial residual norm from partials; every
 // workgroup recomputes the two sums (same order -> same value), workgroup 0 publishes the state; p = r
-__global__ __launch_bounds__(TPB) void k_cg_init(size_t len, CGState *st, const double *__restrict__ part_rr, int nrr,
-                                                 const double *__restrict__ part_b, int nb, double tol,
-                                                 const double *__restrict__ r, double *__restrict__ p, Guard g) {
+// (one workgroup; the direction of iteration 0 is r itself -- its tail is always the k = 0 restart, which
+// sets p = 2 r_true without reading the old p -- so no p = r copy is made)
+__global__ __launch_bounds__(TPB) void k_cg_init(CGState *st, const double *__restrict__ part_rr, int nrr,
+                                                 const double *__restrict__ part_b, int nb, double tol, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const double a = sum_partials(part_rr, nrr, sh);
     const double b = sum_partials(part_b, nb, sh);
     const bool conv = sqrt(a) / b < tol;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->rr = a; st->bnorm = b; st->beta = 0.0; st->iter = 0; st->nan = 0; st->pad = 0;
-        st->done = conv ? 2 : 0;
-    }
-    if (conv) return;
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) p[i] = r[i];
+    if (!live || threadIdx.x != 0) return;
+    st->rr = a; st->bnorm = b; st->beta = 0.0; st->iter = 0; st->nan = 0; st->pad = 0;
+    st->done = conv ? 2 : 0;
 }
 
 // x += alpha p, r -= alpha Q, partial ||r||^2; alpha = rr / (p.Q) from device scalars (lorads_cgs.c:181-189)
 __global__ __launch_bounds__(TPB) void k_cg_update(size_t len, const CGState *st, const double *__restrict__ part_pq, int npq,
-                                                   double *__restrict__ x, double *__restrict__ r,
-                                                   const double *__restrict__ p, const double *__restrict__ Q,
-                                                   double *__restrict__ part_rr, Guard g) {
+                                                   double *__restrict__ x, double *r, const double *p,
+                                                   const double *__restrict__ Q, double *__restrict__ part_rr, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
+    const double rr = st->rr; // issued before the partial sums so that the loads overlap
     const double pq = sum_partials(part_pq, npq, sh);
-    const double alpha = st->rr / pq;
+    const double alpha = rr / pq;
+    if (!live) return;
     double local = 0.0;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
-        x[i] += alpha * p[i];
+        const double pv = p[i]; // p may alias r (iteration 0): read both before writing r
+        x[i] += alpha * pv;
         const double rv = r[i] - alpha * Q[i];
         r[i] = rv;
         local += rv * rv;
@@ -423,16 +427,18 @@ __global__ __launch_bounds__(TPB) void k_cg_update(size_t len, const CGState *st
 __global__ __launch_bounds__(TPB) void k_cg_check(CGState *st, int kind, const double *__restrict__ part_a, int na, double tol,
                                                   int maxiter, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
+    const double rr_old = st->rr, bnorm = st->bnorm; // issued before the partial sums: the loads overlap
+    const int it = st->iter;
     const double a = sum_partials(part_a, na, sh);
-    if (threadIdx.x != 0) return;
+    if (!live || threadIdx.x != 0) return;
     if (kind == CHK_ITER) { // lorads_cgs.c:189-194, :217-224
-        st->iter += 1;
+        st->iter = it + 1;
         if (a != a) st->nan = 1;
-        st->beta = a / st->rr;
+        st->beta = a / rr_old;
         st->rr = a;
-        if (sqrt(a) / st->bnorm < tol) st->done = 1;
-        else if (st->iter >= maxiter) st->done = 3;
+        if (sqrt(a) / bnorm < tol) st->done = 1;
+        else if (it + 1 >= maxiter) st->done = 3;
     } else { // restart: true residual, then beta = qTrNew/qTr = 1 (:195-221)
         st->rr = a;
         st->beta = 1.0;
@@ -500,9 +506,9 @@ __global__ __launch_bounds__(TPB) void k_dot(size_t len, const double *__restric
 __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ part, int n, double scale, int accumulate,
                                                   double *out, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     const double t = sum_partials(part, n, sh);
-    if (threadIdx.x == 0) *out = accumulate ? *out + scale * t : scale * t;
+    if (live && threadIdx.x == 0) *out = accumulate ? *out + scale * t : scale * t;
 }
 enum { SOP_ALPHA = 0, SOP_W = 1, SOP_BETA = 2 };
 // scalar algebra of the two-loop recursion
@@ -515,7 +521,7 @@ __global__ void k_scalar_op(int op, const double *dot, double *alpha, double *be
 __global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restrict__ b, const double *__restrict__ csum,
                                                     const double *__restrict__ lambda, double *out, Guard g) {
     __shared__ double sh[4];
-    if (blocked(g)) return;
+    const bool live = !blocked(g);
     double v = 0.0, d = 0.0;
     for (int i = threadIdx.x; i < m; i += TPB) {
         const double t = b[i] - csum[i];
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restr
     }
     v = block_sum(v, sh);
     d = block_sum(d, sh);
-    if (threadIdx.x == 0) { out[0] = v; out[1] = d; }
+    if (live && threadIdx.x == 0) { out[0] = v; out[1] = d; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -599,6 +605,8 @@ struct Block {
     double *wtmp = nullptr;   // compact weights inside the CG operator
     int *c_row = nullptr, *c_col = nullptr;
     double *c_val = nullptr;
+    bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
+    double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
@@ -811,7 +819,7 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     if (upload(&B.row_idx, v_rowidx) || upload(&B.a_ptr, v_aptr) || upload(&B.a_e, a_e) || upload(&B.a_val, v_aval) ||
         upload(&B.c_row, v_crow) || upload(&B.c_col, v_ccol) || upload(&B.c_val, v_cval))
         return 1;
-    if (dalloc(&B.T, (size_t)B.pa.ne) || dalloc(&B.cv, (size_t)B.nrow) || dalloc(&B.wtmp, (size_t)B.nrow)) return 1;
+    if (dalloc(&B.T, (size_t)B.pa.ne) || dalloc(&B.T2, (size_t)B.pa.ne) || dalloc(&B.cv, (size_t)B.nrow) || dalloc(&B.wtmp, (size_t)B.nrow)) return 1;
     HC(hipMemset(B.cv, 0, sizeof(double) * (size_t)std::max(B.nrow, 1)));
     // Max-Cut fast path
     bool diag = B.nrow > 0;
@@ -950,11 +958,16 @@ int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const doubl
 }
 
 // cv = A_k(sym(X Y^T))   (LORADSInitConstrVal, lorads_alg_common.c:71-76) and, per `mode`, the running m-vector
+// T(U,V) is kept in B.T (and reused by the next solve's initial residual, whose pair dots are the same
+// numbers); every other pair goes through B.T2
 void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, double scale, double *cv, int mode, double *vec,
                 Guard g) {
     if (B.nrow == 0) return;
-    pairdots(c, B.pa, X, Y, B.r, B.T, g);
-    LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T, scale, cv, mode, B.row_idx, vec, g);
+    const bool uv = (X == c->U + B.off && Y == c->V + B.off);
+    double *T = uv ? B.T : B.T2;
+    pairdots(c, B.pa, X, Y, B.r, T, g);
+    if (uv) B.t_uv_valid = true;
+    LAUNCH(k_cv, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, T, scale, cv, mode, B.row_idx, vec, g);
 }
 void sval(lorads_hip_ctx *c, const Pattern &P, bool with_c, int mode, const WArgs &wa, Guard g, CGState *reset = nullptr,
           int nreset = 0) {
@@ -977,7 +990,12 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
     if (B.diag_only) {
         grid = op_diag(c, B, V, mode, x, rhs, out, part, g);
     } else {
-        pairdots(c, B.pa, x, V, B.r, B.T, g);
+        // x and V are this cone's (U,V) in either order and B.T already holds their pair dots
+        const bool is_uv = (x == c->U + B.off && V == c->V + B.off) || (x == c->V + B.off && V == c->U + B.off);
+        if (!(is_uv && B.t_uv_valid)) {
+            pairdots(c, B.pa, x, V, B.r, B.T, g);
+            B.t_uv_valid = is_uv;
+        }
         if (B.has_gram) {
             LAUNCH(k_sgram, nblocks_for((size_t)B.pa.ne, TPB / 8), B.pa.ne, B.g_ptr, B.g_col, B.g_val, B.T, B.pa.S, g);
         } else {
@@ -1037,16 +1055,17 @@ void solve_front(lorads_hip_ctx *c, const Solve &s, double rho, double tol, CGSt
     sval(c, B.pu, true, W_ADMM, wa, s.front, reset, nreset);
     const int nb1 = spmm(c, B, B.pu, s.V, OP_RHS, nullptr, nullptr, rho, rhs, pB, s.front);
     const int na = apply_operator(c, B, s.V, s.x, OP_RES, rhs, r, pA, s.front);
-    LAUNCH(k_cg_init, s.gv, s.len, s.st, pA, na, pB, nb1, tol, r, p, s.front);
+    LAUNCH(k_cg_init, 1, s.st, pA, na, pB, nb1, tol, s.front);
 }
 // body of CG iteration k up to and including the convergence test (lorads_cgs.c:180-194)
-void solve_iter_body(lorads_hip_ctx *c, const Solve &s, double tol, int maxit) {
+void solve_iter_body(lorads_hip_ctx *c, const Solve &s, int k, double tol, int maxit) {
     Block &B = *s.B;
-    double *r = c->cr + B.off, *p = c->cp + B.off, *Q = c->cQ + B.off;
+    double *r = c->cr + B.off, *p = k == 0 ? c->cr + B.off : c->cp + B.off, *Q = c->cQ + B.off; // p_0 = r_0
     double *pA = part_slot(c, 0), *pC = part_slot(c, 2);
     const Guard g{&s.st->done, s.front.need};
     const int npq = apply_operator(c, B, s.V, p, OP_CG, nullptr, Q, pA, g);
     LAUNCH(k_cg_update, s.gv, s.len, s.st, pA, npq, s.x, r, p, Q, pC, g);
+    B.t_uv_valid = false; // x (= U or V) moved
     LAUNCH(k_cg_check, 1, s.st, (int)CHK_ITER, pC, s.gv, tol, maxit, g);
 }
 // tail of CG iteration k: restart with the true residual when k % 20 == 0 (incl. k = 0), new direction (:195-228)
@@ -1067,7 +1086,7 @@ void solve_iter_tail(lorads_hip_ctx *c, const Solve &s, int k, double tol, int m
 void solve_iters(lorads_hip_ctx *c, const Solve &s, int k0, int k1, double tol, int maxit) {
     for (int k = k0; k < k1; ++k) {
         if (k > k0) solve_iter_tail(c, s, k - 1, tol, maxit);
-        solve_iter_body(c, s, tol, maxit);
+        solve_iter_body(c, s, k, tol, maxit);
     }
 }
 // constrVal[k] <- A_k(sym(U V^T)) and constrValSum += new - old (lorads_alg_common.c:199-203)
@@ -1195,6 +1214,7 @@ int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_ev
         first = stg;
         resume = c->h_st[stg].iter;
         c->n_resume++;
+        for (auto &B : c->blk) B.t_uv_valid = false; // kernels after the miss did not run: recompute
     }
     return 0;
 }
@@ -1250,7 +1270,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &B : c->blk) {
         B.pa.release(); B.pu.release();
-        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.cv); hipFree(B.wtmp);
+        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.T2); hipFree(B.cv); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
@@ -1294,6 +1314,7 @@ int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
 }
 
 int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
+    for (auto &B : c->blk) B.t_uv_valid = false; // U is overwritten by the direction D
     const size_t n = c->all_elem;
     const int gv = grid1d(n);
     double *D = c->U;
@@ -1427,13 +1448,19 @@ int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
     return read_scalars(c, 4, 1, dobj);
 }
 
+static void invalidate_t(lorads_hip_ctx *c) {
+    for (auto &B : c->blk) B.t_uv_valid = false;
+}
+
 int lorads_hip_alm_to_admm(lorads_hip_ctx *c) {
+    invalidate_t(c);
     HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
     HC(hipMemcpyAsync(c->U, c->V, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
 int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
+    invalidate_t(c);
     LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, NOGUARD);
     HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
     return 0;
@@ -1452,6 +1479,7 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
     double *base = mat_base(c, which);
     if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
     Block &B = c->blk[k];
+    B.t_uv_valid = false;
     std::vector<double> rm((size_t)B.n * B.r);
     for (int j = 0; j < B.r; ++j)
         for (int i = 0; i < B.n; ++i) rm[(size_t)i * B.r + j] = cm[(size_t)j * B.n + i];
@@ -1508,6 +1536,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
         }
     }
     free_factors(c);
+    invalidate_t(c);
     for (int k = 0; k < c->nb; ++k) { c->blk[k].r = nr[k]; }
     if (alloc_factors(c)) return 1;
     for (int a = 0; a < 4; ++a)
