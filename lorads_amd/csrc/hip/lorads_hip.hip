@@ -274,7 +274,7 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
                                               const int *__restrict__ adj_e, const double *__restrict__ S,
                                               const double *__restrict__ X, int r, int mode, const double *__restrict__ xin,
                                               const double *__restrict__ rhs, double rho, double *__restrict__ out,
-                                              double *__restrict__ part, Guard g) {
+                                              double *__restrict__ part, Guard g, const double *__restrict__ dense_add) {
     __shared__ double sh[4];
     const bool live = !blocked(g);
     constexpr int W = V2 ? 2 : 1;
@@ -282,10 +282,14 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
     const bool act = row < n;
     const int rowc = act ? row : 0;
     double acc[NS][W];
+    // dense part of (C + sum_i w_i A_i) X, computed by k_dense_cx, when C is stored dense
+    if (dense_add) Slice<LG, V2, NS>::load(dense_add + (size_t)rowc * r, r, lane, acc);
+    else {
 #pragma unroll
-    for (int c = 0; c < NS; ++c)
+        for (int c = 0; c < NS; ++c)
 #pragma unroll
-        for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
+            for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
+    }
     const int t0 = adj_ptr[rowc], t1 = act ? adj_ptr[rowc + 1] : t0;
     // epilogue operands are fetched up front: the kernel is bound by its chain of dependent loads
     // (row pointer -> neighbour index -> coefficient / neighbour row), not by bandwidth
@@ -383,6 +387,58 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
     }
     const double t = block_sum(act ? local : 0.0, sh);
     if (live && threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// Dense objective matrix: W = C X with C dense symmetric (n_pad x n_pad row-major, zero padded) and X n x r
+// row-major -- the reference's dense branch (unpack + dsymm, lorads_sdp_data.c:646-671) -- on the FP64 matrix
+// cores: v_mfma_f64_16x16x4_f64, one wave per 16-row strip x all column tiles, X staged through LDS in
+// 32-row slabs shared by the 4 waves of the workgroup (each C element is read once from HBM; 2 n^2 r flop
+// over 8 n^2 bytes = r/4 flop/B).  Lane l = (i = l & 15, g = l >> 4) loads C[row0+i][k0+4g .. +3] (32 B) and
+// feeds MFMA t (t = 0..3) with a = C[row0+i][k0+4g+t], b = X[k0+4g+t][col]; the k index a lane group stands
+// for only has to agree between A and B.  D layout of the f64 form: col = l & 15, row = (l >> 4) + 4 reg.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <int NT> // column tiles of 16 (r <= 16 NT)
+__global__ __launch_bounds__(TPB) void k_dense_cx(int n, int npad, const double *__restrict__ Cf, const double *__restrict__ X,
+                                                  int r, double *__restrict__ Wout, Guard g) {
+    extern __shared__ __attribute__((aligned(16))) double xs[]; // [32][16 NT]
+    const bool live = !blocked(g);
+    constexpr int RP = 16 * NT;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 15, gk = l >> 4;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    v4f64 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const double *crow = Cf + (size_t)(row0 + i) * npad;
+    for (int k0 = 0; k0 < npad; k0 += 32) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * RP; idx += TPB) { // stage X[k0 .. k0+31][0 .. RP), zero padded
+            const int kk = idx / RP, j = idx - kk * RP;
+            const int k = k0 + kk;
+            xs[idx] = (k < n && j < r) ? X[(size_t)k * r + j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const double2 c01 = *(const double2 *)(crow + k0 + 16 * half + 4 * gk);
+            const double2 c23 = *(const double2 *)(crow + k0 + 16 * half + 4 * gk + 2);
+            const double cv4[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double *xr = xs + (16 * half + 4 * gk + t) * RP + i;
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv4[t], xr[16 * ct], acc[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = row0 + gk + 4 * q, col = 16 * ct + i;
+            if (row < n && col < r) Wout[(size_t)row * r + col] = acc[ct][q];
+        }
 }
 
 // start of CGSolve (lorads_cgs.c:115,149-172): ||b||_1 and the initial residual norm from partials; every
@@ -495,12 +551,13 @@ __global__ void k_use_grad(size_t len, const double *ip, const double *__restric
         D[i] = -G[i];
 }
 __global__ __launch_bounds__(TPB) void k_dot(size_t len, const double *__restrict__ x, const double *__restrict__ y,
-                                             double *__restrict__ part) {
+                                             double *__restrict__ part, Guard g) {
     __shared__ double sh[4];
+    const bool live = !blocked(g);
     double local = 0.0;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) local += x[i] * y[i];
     const double t = block_sum(local, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (live && threadIdx.x == 0) part[blockIdx.x] = t;
 }
 // out (= or +=) scale * sum(part)
 __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ part, int n, double scale, int accumulate,
@@ -605,6 +662,10 @@ struct Block {
     double *wtmp = nullptr;   // compact weights inside the CG operator
     int *c_row = nullptr, *c_col = nullptr;
     double *c_val = nullptr;
+    bool dense_c = false;     // C stored dense (reference rule nnz > 0.1 n(n+1)/2): C X runs on MFMA
+    int npad = 0;
+    double *Cfull = nullptr;  // npad x npad row-major, symmetric, zero padded
+    double *Wd = nullptr;     // n x r result of C X
     bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
@@ -799,9 +860,20 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     build_adjacency(B.n, uniqA, hpA);
     build_transpose((int)uniqA.size(), hb.nrow, hb.a_ptr, a_e, hb.a_val, hpA);
     if (upload_pattern(B.pa, hpA, nullptr)) return 1;
-    // union pattern C u A
+    // dense objective (the reference's rule for a dense coefficient, lorads_sdp_data.c:818-821)
+    B.dense_c = (double)B.nc > 0.1 * (double)((int64_t)B.n * (B.n + 1) / 2) && B.r <= 128;
+    if (B.dense_c) {
+        B.npad = (B.n + 63) / 64 * 64;
+        std::vector<double> cf((size_t)B.npad * B.npad, 0.0);
+        for (int t = 0; t < B.nc; ++t) {
+            cf[(size_t)hb.c_row[t] * B.npad + hb.c_col[t]] += hb.c_val[t];
+            if (hb.c_row[t] != hb.c_col[t]) cf[(size_t)hb.c_col[t] * B.npad + hb.c_row[t]] += hb.c_val[t];
+        }
+        if (upload(&B.Cfull, cf)) return 1;
+    }
+    // union pattern C u A (A only when C is dense: the dense part is added by k_dense_cx)
     posU = posA;
-    for (int t = 0; t < B.nc; ++t) posU.push_back({hb.c_row[t], hb.c_col[t]});
+    for (int t = 0; t < B.nc && !B.dense_c; ++t) posU.push_back({hb.c_row[t], hb.c_col[t]});
     std::vector<std::pair<int, int>> uniqU;
     std::vector<int> u_idx;
     unique_positions(posU, uniqU, u_idx);
@@ -810,7 +882,7 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     std::vector<int> a_eU(u_idx.begin(), u_idx.begin() + B.na);
     build_transpose((int)uniqU.size(), hb.nrow, hb.a_ptr, a_eU, hb.a_val, hpU);
     std::vector<double> cbase(uniqU.size(), 0.0);
-    for (int t = 0; t < B.nc; ++t) cbase[u_idx[B.na + t]] += hb.c_val[t];
+    for (int t = 0; t < B.nc && !B.dense_c; ++t) cbase[u_idx[B.na + t]] += hb.c_val[t];
     if (upload_pattern(B.pu, hpU, &cbase)) return 1;
     // constraint CSR + misc
     std::vector<int> v_rowidx(hb.row_idx, hb.row_idx + hb.nrow), v_aptr(hb.a_ptr, hb.a_ptr + hb.nrow + 1);
@@ -851,6 +923,8 @@ int alloc_factors(lorads_hip_ctx *c) {
         if (dalloc(a, n)) return 1;
         HC(hipMemset(*a, 0, sizeof(double) * std::max<size_t>(n, 1)));
     }
+    for (auto &B : c->blk)
+        if (B.dense_c && dalloc(&B.Wd, (size_t)B.n * B.r)) return 1;
     c->ring.resize(c->L);
     for (auto &nd : c->ring) {
         if (dalloc(&nd.s, n) || dalloc(&nd.y, n)) return 1;
@@ -863,6 +937,7 @@ int alloc_factors(lorads_hip_ctx *c) {
 void free_factors(lorads_hip_ctx *c) {
     double *arrs[] = {c->R, c->U, c->V, c->G, c->cr, c->cp, c->cQ, c->rhs, c->Dtmp};
     for (auto a : arrs) hipFree(a);
+    for (auto &B : c->blk) { hipFree(B.Wd); B.Wd = nullptr; }
     for (auto &nd : c->ring) { hipFree(nd.s); hipFree(nd.y); }
     c->ring.clear();
 }
@@ -935,12 +1010,31 @@ void pairdots(lorads_hip_ctx *c, const Pattern &P, const double *X, const double
 }
 // returns the number of partials written
 int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, int mode, const double *xin, const double *rhs,
-         double rho, double *out, double *part, Guard g) {
+         double rho, double *out, double *part, Guard g, const double *dense_add = nullptr) {
     const Shape sh = shape_for(B.r);
     const int grid = nblocks_for((size_t)B.n, TPB / sh.lg);
     SHAPE_DISPATCH(sh, LAUNCH((k_spmm<LG_, V2_, NS_>), grid, B.n, P.adj_ptr, P.adj_col, P.adj_e, P.S, X, B.r, mode, xin, rhs, rho,
-                              out, part, g));
+                              out, part, g, dense_add));
     return grid;
+}
+// W = C X on the matrix cores (dense objective only)
+int dense_cx(lorads_hip_ctx *c, const Block &B, const double *X, double *W, Guard g) {
+    const int nt = (B.r + 15) / 16, grid = B.npad / 64;
+    const size_t lds = sizeof(double) * 32 * 16 * (size_t)nt;
+#define DCX(NTV) hipLaunchKernelGGL(k_dense_cx<NTV>, dim3(grid), dim3(TPB), lds, c->stream, B.n, B.npad, B.Cfull, X, B.r, W, g)
+    switch (nt) {
+    case 1: DCX(1); break;
+    case 2: DCX(2); break;
+    case 3: DCX(3); break;
+    case 4: DCX(4); break;
+    case 5: DCX(5); break;
+    case 6: DCX(6); break;
+    case 7: DCX(7); break;
+    case 8: DCX(8); break;
+    default: return 1;
+    }
+#undef DCX
+    return 0;
 }
 int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs, double *out,
             double *part, Guard g) {
@@ -951,6 +1045,13 @@ int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const 
 }
 int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part, Guard g) {
     if (B.nc == 0) return 0;
+    if (B.dense_c) { // <C, sym(X Y^T)> = sum_p X_p . (C Y)_p for symmetric C
+        dense_cx(c, B, Y, B.Wd, g);
+        const size_t len = (size_t)B.n * B.r;
+        const int grid = grid1d(len);
+        LAUNCH(k_dot, grid, len, X, B.Wd, part, g);
+        return grid;
+    }
     const Shape sh = shape_for(B.r);
     const int grid = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
     SHAPE_DISPATCH(sh, LAUNCH((k_obj<LG_, V2_, NS_>), grid, B.nc, B.c_row, B.c_col, B.c_val, X, Y, B.r, part, g));
@@ -1053,7 +1154,8 @@ void solve_front(lorads_hip_ctx *c, const Solve &s, double rho, double tol, CGSt
     WArgs wa{};
     wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.cv = B.cv; wa.row_idx = B.row_idx; wa.rho = rho;
     sval(c, B.pu, true, W_ADMM, wa, s.front, reset, nreset);
-    const int nb1 = spmm(c, B, B.pu, s.V, OP_RHS, nullptr, nullptr, rho, rhs, pB, s.front);
+    if (B.dense_c) dense_cx(c, B, s.V, B.Wd, s.front);
+    const int nb1 = spmm(c, B, B.pu, s.V, OP_RHS, nullptr, nullptr, rho, rhs, pB, s.front, B.dense_c ? B.Wd : nullptr);
     const int na = apply_operator(c, B, s.V, s.x, OP_RES, rhs, r, pA, s.front);
     LAUNCH(k_cg_init, 1, s.st, pA, na, pB, nb1, tol, s.front);
 }
@@ -1178,7 +1280,7 @@ int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) { return 
 // flat dot -> device scalar slot (+ cross-rank sum)
 int dot_to_slot(lorads_hip_ctx *c, const double *x, const double *y, int slot) {
     int g = grid1d(c->all_elem);
-    LAUNCH(k_dot, g, c->all_elem, x, y, part_slot(c, 3));
+    LAUNCH(k_dot, g, c->all_elem, x, y, part_slot(c, 3), NOGUARD);
     LAUNCH(k_finalize, 1, part_slot(c, 3), g, 1.0, 0, c->scal + slot, NOGUARD);
     return allreduce_dev(c, c->scal + slot, 1);
 }
@@ -1270,7 +1372,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &B : c->blk) {
         B.pa.release(); B.pu.release();
-        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.T); hipFree(B.T2); hipFree(B.cv); hipFree(B.wtmp);
+        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.cv); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
@@ -1306,7 +1408,9 @@ int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
-        int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), NOGUARD);
+        if (B.dense_c) dense_cx(c, B, c->R + B.off, B.Wd, NOGUARD);
+        int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), NOGUARD,
+                     B.dense_c ? B.Wd : nullptr);
         LAUNCH(k_finalize, 1, part_slot(c, 0), g, 1.0, 1, c->scal + 8, NOGUARD);
     }
     if (allreduce_dev(c, c->scal + 8, 1)) return 1;
@@ -1443,7 +1547,7 @@ int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
 
 int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
     const int g = std::min(grid1d((size_t)c->m), 256);
-    LAUNCH(k_dot, g, (size_t)c->m, c->b, c->lambda, part_slot(c, 7));
+    LAUNCH(k_dot, g, (size_t)c->m, c->b, c->lambda, part_slot(c, 7), NOGUARD);
     LAUNCH(k_finalize, 1, part_slot(c, 7), g, 1.0, 0, c->scal + 4, NOGUARD);
     return read_scalars(c, 4, 1, dobj);
 }
@@ -1470,6 +1574,7 @@ int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
     for (auto &B : c->blk) {
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
+        if (B.dense_c) LAUNCH(k_scale, grid1d((size_t)B.npad * B.npad), (size_t)B.npad * B.npad, s, B.Cfull);
     }
     if (c->m) LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, s, c->lambda);
     return 0;

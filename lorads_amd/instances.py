@@ -223,6 +223,7 @@ NAMED = {
     "coupled3x70": lambda: coupled_blocks(3, 70, 30, 3100, n_diag=1, n_off=2, r0=2, c_edges=60),
     "densec40": lambda: randsparse(40, 20, 777, n_diag=1, n_off=2, r0=2, dense_c=True),
     "matcomp60": lambda: matcomp(30, 30, 200, 3, 50),
+    "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
     # timing / log-level instances
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
     "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini

@@ -43,7 +43,8 @@ def _gen(name):
     return path
 
 
-@pytest.mark.parametrize("name,tlr", [("maxcut800", 2.0), ("maxcut4000", 3.0), ("rand4000", 3.0)])
+@pytest.mark.parametrize("name,tlr", [("maxcut800", 2.0), ("maxcut4000", 3.0), ("rand4000", 3.0), ("densec300", 2.0),
+                                      ("densec300", 7.0)])
 def test_functions_vs_oracle_midsize(built, name, tlr):
     """same seeded input through both tables, function by function (sizes the oracle finishes in seconds)"""
     path = common.instance_path(name) if name == "maxcut800" else _gen(name)
