@@ -391,54 +391,72 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
 
 // Dense objective matrix: W = C X with C dense symmetric (n_pad x n_pad row-major, zero padded) and X n x r
 // row-major -- the reference's dense branch (unpack + dsymm, lorads_sdp_data.c:646-671) -- on the FP64 matrix
-// cores: v_mfma_f64_16x16x4_f64, one wave per 16-row strip x all column tiles, X staged through LDS in
-// 32-row slabs shared by the 4 waves of the workgroup (each C element is read once from HBM; 2 n^2 r flop
-// over 8 n^2 bytes = r/4 flop/B).  Lane l = (i = l & 15, g = l >> 4) loads C[row0+i][k0+4g .. +3] (32 B) and
-// feeds MFMA t (t = 0..3) with a = C[row0+i][k0+4g+t], b = X[k0+4g+t][col]; the k index a lane group stands
-// for only has to agree between A and B.  D layout of the f64 form: col = l & 15, row = (l >> 4) + 4 reg.
+// cores: v_mfma_f64_16x16x4_f64.  Workgroup (bx, by): 64 rows of C (16 per wave) x the by-th K range
+// (split-K over workgroups so that the grid fills 256 CUs; the KS partial results are summed in a fixed
+// order by k_sum_slabs).  The 4 waves share each 32-row slab of X, staged through LDS as a plain linear copy
+// (unpadded [32][r]; the column padding to 16 NT is done when the B fragment is read).  Each C element is read
+// once from HBM: 2 n^2 r flop over 8 n^2 bytes = r/4 flop/B.  Lane l = (i = l & 15, g = l >> 4) loads
+// C[row0+i][k+4g .. +3] (32 B) and feeds MFMA t (t = 0..3) with a = C[row0+i][k+4g+t], b = X[k+4g+t][col];
+// the k index a lane group stands for only has to agree between A and B.  D layout of the f64 form:
+// col = l & 15, row = (l >> 4) + 4 reg.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int NT> // column tiles of 16 (r <= 16 NT)
-__global__ __launch_bounds__(TPB) void k_dense_cx(int n, int npad, const double *__restrict__ Cf, const double *__restrict__ X,
-                                                  int r, double *__restrict__ Wout, Guard g) {
-    extern __shared__ __attribute__((aligned(16))) double xs[]; // [32][16 NT]
+__global__ __launch_bounds__(TPB) void k_dense_cx(int n, int npad, int krange, const double *__restrict__ Cf,
+                                                  const double *__restrict__ X, int r, double *__restrict__ Wpart, Guard g) {
+    extern __shared__ __attribute__((aligned(16))) double xs[]; // [32][r]
     const bool live = !blocked(g);
-    constexpr int RP = 16 * NT;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 15, gk = l >> 4;
     const int row0 = blockIdx.x * 64 + wave * 16;
+    const int kbeg = blockIdx.y * krange;
     v4f64 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const double *crow = Cf + (size_t)(row0 + i) * npad;
-    for (int k0 = 0; k0 < npad; k0 += 32) {
+    // column of the B fragment per tile, clamped into the row; padded columns are masked to 0
+    int colc[NT];
+    double colm[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int col = 16 * ct + i;
+        colc[ct] = col < r ? col : 0;
+        colm[ct] = col < r ? 1.0 : 0.0;
+    }
+    const double *crow = Cf + (size_t)(row0 + i) * npad + 4 * gk;
+    const size_t xlen = (size_t)n * r;
+    for (int k0 = kbeg; k0 < kbeg + krange; k0 += 32) {
+        const double2 c0 = *(const double2 *)(crow + k0), c1 = *(const double2 *)(crow + k0 + 2);
+        const double2 c2 = *(const double2 *)(crow + k0 + 16), c3 = *(const double2 *)(crow + k0 + 18);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < 32 * RP; idx += TPB) { // stage X[k0 .. k0+31][0 .. RP), zero padded
-            const int kk = idx / RP, j = idx - kk * RP;
-            const int k = k0 + kk;
-            xs[idx] = (k < n && j < r) ? X[(size_t)k * r + j] : 0.0;
-        }
+        const size_t xoff = (size_t)k0 * r;
+        for (int idx = threadIdx.x; idx < 32 * r; idx += TPB) // rows beyond n are zero (C is zero padded too)
+            xs[idx] = xoff + idx < xlen ? X[xoff + idx] : 0.0;
         __syncthreads();
+        const double cv8[8] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const double2 c01 = *(const double2 *)(crow + k0 + 16 * half + 4 * gk);
-            const double2 c23 = *(const double2 *)(crow + k0 + 16 * half + 4 * gk + 2);
-            const double cv4[4] = {c01.x, c01.y, c23.x, c23.y};
+        for (int t = 0; t < 8; ++t) {
+            const double *xr = xs + (16 * (t >> 2) + 4 * gk + (t & 3)) * r;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double *xr = xs + (16 * half + 4 * gk + t) * RP + i;
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv4[t], xr[16 * ct], acc[ct], 0, 0, 0);
-            }
+            for (int ct = 0; ct < NT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv8[t], xr[colc[ct]] * colm[ct], acc[ct], 0, 0, 0);
         }
     }
     if (!live) return;
+    double *Wo = Wpart + (size_t)blockIdx.y * n * r;
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int row = row0 + gk + 4 * q, col = 16 * ct + i;
-            if (row < n && col < r) Wout[(size_t)row * r + col] = acc[ct][q];
+            if (row < n && col < r) Wo[(size_t)row * r + col] = acc[ct][q];
         }
+}
+// W = sum of the split-K slabs, fixed order
+__global__ void k_sum_slabs(size_t len, int ks, const double *__restrict__ part, double *__restrict__ W, Guard g) {
+    const bool live = !blocked(g);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+        double v = part[i];
+        for (int k = 1; k < ks; ++k) v += part[(size_t)k * len + i];
+        if (live) W[i] = v;
+    }
 }
 
 // start of CGSolve (lorads_cgs.c:115,149-172): ||b||_1 and the initial residual norm from partials; every
@@ -666,6 +684,8 @@ struct Block {
     int npad = 0;
     double *Cfull = nullptr;  // npad x npad row-major, symmetric, zero padded
     double *Wd = nullptr;     // n x r result of C X
+    double *Wpart = nullptr;  // split-K slabs of it
+    int ksplit = 1;
     bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
@@ -864,6 +884,9 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     B.dense_c = (double)B.nc > 0.1 * (double)((int64_t)B.n * (B.n + 1) / 2) && B.r <= 128;
     if (B.dense_c) {
         B.npad = (B.n + 63) / 64 * 64;
+        // split K over workgroups until the grid has >= 512 of them (K range a multiple of 32)
+        B.ksplit = 1;
+        while (B.ksplit < 16 && (B.npad / 64) * B.ksplit < 512 && (B.npad / (2 * B.ksplit)) % 32 == 0) B.ksplit *= 2;
         std::vector<double> cf((size_t)B.npad * B.npad, 0.0);
         for (int t = 0; t < B.nc; ++t) {
             cf[(size_t)hb.c_row[t] * B.npad + hb.c_col[t]] += hb.c_val[t];
@@ -924,7 +947,7 @@ int alloc_factors(lorads_hip_ctx *c) {
         HC(hipMemset(*a, 0, sizeof(double) * std::max<size_t>(n, 1)));
     }
     for (auto &B : c->blk)
-        if (B.dense_c && dalloc(&B.Wd, (size_t)B.n * B.r)) return 1;
+        if (B.dense_c && (dalloc(&B.Wd, (size_t)B.n * B.r) || dalloc(&B.Wpart, (size_t)B.ksplit * B.n * B.r))) return 1;
     c->ring.resize(c->L);
     for (auto &nd : c->ring) {
         if (dalloc(&nd.s, n) || dalloc(&nd.y, n)) return 1;
@@ -937,7 +960,7 @@ int alloc_factors(lorads_hip_ctx *c) {
 void free_factors(lorads_hip_ctx *c) {
     double *arrs[] = {c->R, c->U, c->V, c->G, c->cr, c->cp, c->cQ, c->rhs, c->Dtmp};
     for (auto a : arrs) hipFree(a);
-    for (auto &B : c->blk) { hipFree(B.Wd); B.Wd = nullptr; }
+    for (auto &B : c->blk) { hipFree(B.Wd); hipFree(B.Wpart); B.Wd = B.Wpart = nullptr; }
     for (auto &nd : c->ring) { hipFree(nd.s); hipFree(nd.y); }
     c->ring.clear();
 }
@@ -1019,9 +1042,10 @@ int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, i
 }
 // W = C X on the matrix cores (dense objective only)
 int dense_cx(lorads_hip_ctx *c, const Block &B, const double *X, double *W, Guard g) {
-    const int nt = (B.r + 15) / 16, grid = B.npad / 64;
-    const size_t lds = sizeof(double) * 32 * 16 * (size_t)nt;
-#define DCX(NTV) hipLaunchKernelGGL(k_dense_cx<NTV>, dim3(grid), dim3(TPB), lds, c->stream, B.n, B.npad, B.Cfull, X, B.r, W, g)
+    const int nt = (B.r + 15) / 16, gx = B.npad / 64, ks = B.ksplit, krange = B.npad / ks;
+    const size_t lds = sizeof(double) * 32 * (size_t)B.r;
+    double *dst = ks == 1 ? W : B.Wpart;
+#define DCX(NTV) hipLaunchKernelGGL(k_dense_cx<NTV>, dim3(gx, ks), dim3(TPB), lds, c->stream, B.n, B.npad, krange, B.Cfull, X, B.r, dst, g)
     switch (nt) {
     case 1: DCX(1); break;
     case 2: DCX(2); break;
@@ -1034,6 +1058,10 @@ int dense_cx(lorads_hip_ctx *c, const Block &B, const double *X, double *W, Guar
     default: return 1;
     }
 #undef DCX
+    if (ks > 1) {
+        const size_t len = (size_t)B.n * B.r;
+        LAUNCH(k_sum_slabs, grid1d(len), len, ks, B.Wpart, W, g);
+    }
     return 0;
 }
 int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs, double *out,
