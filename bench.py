@@ -103,22 +103,62 @@ def admm_steps(be, host, rho, err1, steps, session=None):
     return err1, cg, pobj, dobj
 
 
-def make_allreduce(dist, torch, device):
+def make_allreduce(dist, torch, device, ext_stream=None):
+    """All-reduce hook for the library.  With `ext_stream` (the library's own HIP stream wrapped as a
+    torch ExternalStream) the RCCL collective is enqueued in stream order -- no host synchronisation --
+    otherwise the library has synchronised its stream and we synchronise after the collective."""
     class _Dev:
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
     def fn(ptr, count, on_device):
         if on_device:
-            t = torch.as_tensor(_Dev(ptr, count), device=device)
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
+            if ext_stream is not None:
+                with torch.cuda.stream(ext_stream):
+                    t = torch.as_tensor(_Dev(ptr, count), device=device)
+                    dist.all_reduce(t)   # ordered after the kernels already on the stream; later kernels wait for it
+            else:
+                t = torch.as_tensor(_Dev(ptr, count), device=device)
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
         else:
             a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
             t = torch.from_numpy(a.copy()).to(device)
             dist.all_reduce(t)
             a[:] = t.cpu().numpy()
     return fn
+
+
+def install_allreduce(s, dist, torch, device, world, rank, backend):
+    """Registers the hook; uses the stream-ordered form with RCCL after a self-check through the library
+    (constrValSum filled with rank+1 must come back as world*(world+1)/2), else the synchronising form."""
+    from lorads_amd import host as _h
+    want = world * (world + 1) / 2.0
+
+    def check():
+        s.be.set_vec(_h.VEC_CONSTR_SUM, np.full(s.m, rank + 1.0))
+        s.hip_selfcheck_allreduce()
+        got = s.be.get_vec(_h.VEC_CONSTR_SUM)
+        ok = torch.tensor([1.0 if np.all(got == want) else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item() == 1.0)
+
+    mode = "sync"
+    if backend == "nccl" and os.environ.get("LORADS_ALLREDUCE_SYNC", "0") != "1":
+        try:
+            ext = torch.cuda.ExternalStream(s.hip_stream(), device=device)
+            s.set_allreduce(make_allreduce(dist, torch, device, ext))
+            s.hip_allreduce_stream_ordered(1)
+            if check():
+                mode = "stream-ordered"
+        except Exception as e:  # noqa: BLE001
+            log("stream-ordered all-reduce unavailable: %s" % e)
+    if mode == "sync":
+        s.hip_allreduce_stream_ordered(0)
+        s.set_allreduce(make_allreduce(dist, torch, device, None))
+        if not check():
+            raise RuntimeError("all-reduce hook self-check failed")
+    return mode
 
 
 def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
@@ -195,8 +235,10 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
     s.set_params(verbose=0, timesLogRank=a.times_log_rank, phase1Tol=1e-2, reoptLevel=0)
     s.prepare(world, rank)
     s.attach_hip()
+    ar_mode = None
     if dist:
-        s.set_allreduce(make_allreduce(dist, torch, device))
+        ar_mode = install_allreduce(s, dist, torch, device, world, rank, os.environ.get("LORADS_DIST_BACKEND", "nccl"))
+        log("rank %d: all-reduce hook mode: %s" % (rank, ar_mode))
     be = s.be
     info = s.block_info(0)
     # ---- untimed set-up: phase 1 on the GPU gives the factors, then the hand-off
@@ -260,7 +302,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
             "config": {"workload": "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
                                    % (workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]),
                        "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": world,
-                       "parallelism": "block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration" if world > 1 else "single GPU",
+                       "parallelism": ("block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration (%s)" % ar_mode) if world > 1 else "single GPU",
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (a.times_log_rank, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
             "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x) (k_pairdots+k_cv_from_T+k_sval+k_spmm, or k_op_diag)",

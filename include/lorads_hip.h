@@ -116,6 +116,13 @@ int lorads_hip_get_mat(lorads_hip_ctx *ctx, int32_t which, int32_t blk, double *
 int lorads_hip_set_vec(lorads_hip_ctx *ctx, int32_t which, const double *v);
 int lorads_hip_get_vec(lorads_hip_ctx *ctx, int32_t which, double *v);
 int lorads_hip_set_allreduce(lorads_hip_ctx *ctx, lorads_hip_allreduce_fn fn, void *user);
+/* The library's HIP stream (hipStream_t).  A hook that ENQUEUES its collective on this stream (RCCL
+ * ncclAllReduce(..., stream)) can declare itself stream-ordered: the library then does not synchronise
+ * the host before calling it, so a multi-GPU ADMM iteration still has a single host sync. */
+void *lorads_hip_stream(lorads_hip_ctx *ctx);
+int lorads_hip_set_allreduce_stream_ordered(lorads_hip_ctx *ctx, int32_t on);
+/* all-reduces constrValSum through the hook once (lets the caller validate its hook) */
+int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *ctx);
 
 /* measurement hooks (bench.py): HIP-event timing of the dominant kernels on the library's stream.
  * stats[0..7] = {cg_matvec launches, speculation misses (resumed solves), cg iterations, cg solves,

@@ -722,6 +722,7 @@ struct lorads_hip_ctx {
     int head = 0;
     lorads_hip_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
+    bool ar_stream_ordered = false; // the hook enqueues on our stream (RCCL): no host sync around it
     // profiling
     int prof = 0, prof_every = 8;
     long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
@@ -986,7 +987,7 @@ double *vec_base(lorads_hip_ctx *c, int which) {
 
 int allreduce_dev(lorads_hip_ctx *c, double *buf, int count) {
     if (!c->ar) return 0;
-    HC(hipStreamSynchronize(c->stream));
+    if (!c->ar_stream_ordered) HC(hipStreamSynchronize(c->stream));
     if (c->ar(c->ar_user, buf, count, 1)) return fail_msg("allreduce hook failed");
     return 0;
 }
@@ -1420,6 +1421,22 @@ int lorads_hip_sync(lorads_hip_ctx *c) {
 int lorads_hip_set_allreduce(lorads_hip_ctx *c, lorads_hip_allreduce_fn fn, void *user) {
     c->ar = fn;
     c->ar_user = user;
+    return 0;
+}
+
+int lorads_hip_set_allreduce_stream_ordered(lorads_hip_ctx *c, int32_t on) {
+    c->ar_stream_ordered = on != 0;
+    return 0;
+}
+
+void *lorads_hip_stream(lorads_hip_ctx *c) { return (void *)c->stream; }
+
+/* all-reduce constrValSum through the registered hook (self-check of a hook / of the stream-ordered mode) */
+int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *c) {
+    LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, 1.0, c->csum); // some work on the stream before the collective
+    if (allreduce_dev(c, c->csum, c->m)) return 1;
+    LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, 1.0, c->csum); // and after it
+    HC(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -305,6 +305,9 @@ class Session:
             lib.lorads_hip_profile_read.argtypes = [C.c_void_p, _dp]
             lib.lorads_hip_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
             lib.lorads_hip_sync.argtypes = [C.c_void_p]
+            lib.lorads_hip_stream.restype = C.c_void_p
+            lib.lorads_hip_stream.argtypes = [C.c_void_p]
+            lib.lorads_hip_set_allreduce_stream_ordered.argtypes = [C.c_void_p, C.c_int]
             self.lib.lrd_hip_backend_raw_ctx.restype = C.c_void_p
             self.lib.lrd_hip_backend_raw_ctx.argtypes = [C.POINTER(BackendStruct)]
             self._hiplib = lib
@@ -328,6 +331,20 @@ class Session:
         a, b = C.c_double(), C.c_double()
         _check(lib.lorads_hip_algorithmic_bytes(ctx, blk, C.byref(a), C.byref(b)), "algorithmic_bytes")
         return a.value, b.value
+
+    def hip_stream(self):
+        """hipStream_t of the library as an integer (torch.cuda.ExternalStream takes it)"""
+        lib, ctx = self._hip()
+        return lib.lorads_hip_stream(ctx)
+
+    def hip_allreduce_stream_ordered(self, on):
+        lib, ctx = self._hip()
+        _check(lib.lorads_hip_set_allreduce_stream_ordered(ctx, int(on)), "set_allreduce_stream_ordered")
+
+    def hip_selfcheck_allreduce(self):
+        lib, ctx = self._hip()
+        lib.lorads_hip_selfcheck_allreduce.argtypes = [C.c_void_p]
+        _check(lib.lorads_hip_selfcheck_allreduce(ctx), "selfcheck_allreduce")
 
     def hip_sync(self):
         lib, ctx = self._hip()
