@@ -594,9 +594,11 @@ __global__ void k_scalar_op(int op, const double *dot, double *alpha, double *be
 }
 // one workgroup: out[0] = sum (b-csum)^2, out[1] = b.lambda   (primalInfeasibility, LORADSCalDualObj)
 __global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restrict__ b, const double *__restrict__ csum,
-                                                    const double *__restrict__ lambda, double *out, Guard g) {
+                                                    const double *__restrict__ lambda, double *out, Guard g,
+                                                    const double *__restrict__ obj_part, int nobj) {
     __shared__ double sh[4];
     const bool live = !blocked(g);
+    const double o = obj_part ? sum_partials(obj_part, nobj, sh) : 0.0; // out[2] = <C, R R^T> (one cone, one rank)
     double v = 0.0, d = 0.0;
     for (int i = threadIdx.x; i < m; i += TPB) {
         const double t = b[i] - csum[i];
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restr
     }
     v = block_sum(v, sh);
     d = block_sum(d, sh);
-    if (live && threadIdx.x == 0) { out[0] = v; out[1] = d; }
+    if (live && threadIdx.x == 0) { out[0] = v; out[1] = d; if (obj_part) out[2] = o; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -1283,18 +1285,22 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need) {
     const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
     if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
     bool first_obj = true;
+    const bool fold_obj = c->nb == 1 && !c->ar; // the final kernel sums the objective partials itself
+    int nobj = 0;
     for (auto &B : c->blk) {
         constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
+        if (fold_obj) { nobj = go; continue; }
         if (go) { LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, first_obj ? 0 : 1, c->scal + 2, g); first_obj = false; }
     }
-    if (first_obj) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
+    if (first_obj && !(fold_obj && nobj > 0)) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
     if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part] per evaluation
         HC(hipMemcpyAsync(c->csum + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
         HC(hipMemcpyAsync(c->scal + 2, c->csum + c->m, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
-    LAUNCH(k_eval_final, 1, c->m, c->b, c->csum, c->lambda, c->scal, g);
+    LAUNCH(k_eval_final, 1, c->m, c->b, c->csum, c->lambda, c->scal, g, (fold_obj && nobj > 0) ? part_slot(c, 4) : (const double *)nullptr,
+           nobj);
     return 0;
 }
 
