@@ -105,6 +105,15 @@ int lorads_hip_admm_step(lorads_hip_ctx *ctx, double rho, double cg_tol, int32_t
 int lorads_hip_update_dual_var(lorads_hip_ctx *ctx, double rho);
 int lorads_hip_cal_dual_obj(lorads_hip_ctx *ctx, double *dobj);
 
+/* calculate_dual_infeasibility_solver + dual_infeasible (data/lorads_solver.c:1007-1037,
+ * data/lorads_sdp_conic.c:1286-1349): *sum_neg = sum over this context's cones of
+ * |min(lambda_min(C_k - sum_i lambda_i A_ik), 0)| -- the caller divides by scaleObjHis (1 + ||C||_1) as
+ * :1034-1035 do.  tol, ncv, max_restarts are the ARPACK parameters of the reference (1e-2, 40, 600); the
+ * eigenvalue comes from an on-device thick-restart Lanczos with the same subspace size and stopping rule.
+ * lam_min ([nblocks], may be NULL) receives the per-cone eigenvalue, *matvecs (may be NULL) the S x count. */
+int lorads_hip_dual_infeasibility(lorads_hip_ctx *ctx, double tol, int32_t ncv, int32_t max_restarts, double *sum_neg,
+                                  double *lam_min, int32_t *matvecs);
+
 /* state movers ("mutators outside the table") */
 int lorads_hip_alm_to_admm(lorads_hip_ctx *ctx);        /* LORADS_ALMtoADMM copies, data/lorads_solver.c:968-983 */
 int lorads_hip_average_uv_to_v(lorads_hip_ctx *ctx);    /* averageUV + copyRtoV, main.c:441-448 */

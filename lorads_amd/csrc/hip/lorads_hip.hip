@@ -119,7 +119,7 @@ __device__ __forceinline__ bool blocked(const Guard &g) { return (g.skip && *g.s
 // their stores: the gate loads fly together with the kernel's own first loads.  A blocked kernel computes on
 // whatever is there and writes nothing.
 
-enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2 };
+enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3 };
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
 enum { CHK_ITER = 1, CHK_RESTART = 2 };
 enum { DIR_BETA = 1, DIR_RESTART = 2 };
@@ -237,6 +237,7 @@ __device__ __forceinline__ double weight_of(int mode, const WArgs &a, int i) {
     if (mode == W_COMPACT) return a.w[i];
     const int g = a.row_idx[i];
     if (mode == W_ADMM) return ((a.csum[g] - a.b[g]) - a.cv[i]) * a.rho - a.lambda[g]; // lorads_admm.c:432-445
+    if (mode == W_DUAL) return -a.lambda[g];                                            // data/lorads_solver.c:1011
     return (-a.lambda[g] - a.rho * a.b[g]) + a.rho * a.csum[g];                         // lorads_alm.c:22-26
 }
 // S_e = [cbase_e] + sum over the constraints touching e of weight_i * a
@@ -1739,3 +1740,5 @@ int lorads_hip_algorithmic_bytes(lorads_hip_ctx *c, int32_t k, double *mv, doubl
 }
 
 } // extern "C"
+
+#include "lanczos.inc"

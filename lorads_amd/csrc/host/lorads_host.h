@@ -136,6 +136,9 @@ typedef struct lrd_backend {
     /* OPTIONAL (may be NULL): admm_update_var + cal_obj(UV) + cal_dual_obj + update_dimacs(UV) in one
      * call, same order and results (lorads_admm.c:76-81); out = {cg iterations, pobj, dobj, err1} */
     int (*admm_step)(void *ctx, double rho, double cg_tol, int cg_max_iter, double out[4]);
+    /* OPTIONAL (may be NULL): calculate_dual_infeasibility_solver without its two divisions
+     * (data/lorads_solver.c:1007-1033): sum over this table's cones of |min(lambda_min(C_k - A_k^*(lambda)), 0)| */
+    int (*dual_infeasibility)(void *ctx, double *sum_neg_eig);
 } lrd_backend;
 
 /* iteration states, as the reference's lorads_alm_state / lorads_admm_state
@@ -160,6 +163,8 @@ typedef struct {
     lrd_alm_state alm;
     lrd_admm_state admm;
     double pObjVal, dObjVal, err_constr_l1, err_pdgap; /* dimacError[0], [1] */
+    double err_dual_l1;   /* dimacError[LORADS_DIMAC_ERROR_DUALFEASIBLE_L1]; -1 = not evaluated */
+    double t_dual_infeas; /* seconds spent evaluating it (main.c all_dual_infea) */
     double scaleObjHis;
     int cgIter;     /* cumulative CG iterations of the current ADMM call (ASolver->cgIter) */
     int max_alm_sub_iter; /* the reference's global MAX_ALM_SUB_ITER (lorads_alm.c:7) */
@@ -205,6 +210,7 @@ double lrd_reopt(lrd_params *par, lrd_solver *s, double reopt_param, int reopt_a
 /* whole solve = reference main.c:321-398 (dual infeasibility / level-2 reopt need the ARPACK step
  * and are "next") */
 int lrd_solve(lrd_params *par, lrd_solver *s);
+int lrd_dual_infeasibility(lrd_solver *s); /* data/lorads_solver.c:1007-1037 through the table's optional slot */
 
 /* scalar helpers of the line search (lorads_alm.c:102-228) */
 int lrd_cubic_roots(double a, double b, double c, double d, double res[3]);

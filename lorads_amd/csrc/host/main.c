@@ -15,6 +15,7 @@ int lrd_session_prepare(lrd_session *s, int world, int rank_id);
 int lrd_session_attach(lrd_session *s, const lrd_backend *be);
 int lrd_session_solve(lrd_session *s);
 int lrd_session_results(lrd_session *s, double out[16]);
+int lrd_session_results2(lrd_session *s, double out[4]);
 lrd_problem *lrd_session_problem(lrd_session *s);
 lrd_params *lrd_session_params(lrd_session *s);
 void lrd_session_close(lrd_session *s);
@@ -45,15 +46,23 @@ int main(int argc, char **argv) {
     }
     if (lrd_session_attach(s, &be)) return 1;
     lrd_session_solve(s);
-    double r[16];
+    double r[16], r2[4];
     lrd_session_results(s, r);
+    lrd_session_results2(s, r2);
+    static const char *why[] = {"but the status is unknown", "due to reaching `Official terminate criteria`",
+                                "due to reaching `final terminate criteria`", "due to reaching `the maximum number of iterations`",
+                                "since time limit"};
+    printf("End Program %s:\n", why[(int)r[12] >= 0 && (int)r[12] <= 4 ? (int)r[12] : 0]);
+    /* printRes layout (data/lorads_solver.c:908-922) */
     printf("-----------------------------------------------------------------------\n");
     printf("Objective function Value are:\n\t 1.Primal Objective:            : %10.6e\n\t 2.Dual Objective:              : %10.6e\n",
            r[0], r[1]);
-    printf("Dimacs Error are:\n\t 1.Constraint Violation(1)      : %10.6e\n\t 3.Primal Dual Gap              : %10.6e\n"
-           "\t 5.Constraint Violation(Inf)    : %10.6e\n", r[2], r[3], r[15]);
+    printf("Dimacs Error are:\n\t 1.Constraint Violation(1)      : %10.6e\n\t 2.Dual Infeasibility(1)        : %10.6e\n"
+           "\t 3.Primal Dual Gap              : %10.6e\n\t 5.Constraint Violation(Inf)    : %10.6e\n"
+           "\t 6.Dual Infeasibility(Inf)      : %10.6e\n", r[2], r2[0], r[3], r[15], r2[1]);
     printf("-----------------------------------------------------------------------\n");
-    printf("phase 1: %f s, phase 2: %f s (%d ADMM iterations, %d CG iterations)\n", r[10], r[11], (int)r[13], (int)r[14]);
+    printf("phase 1: %f s, phase 2: %f s (%d ADMM iterations, %d CG iterations), dual infeasibility: %f s\n", r[10], r[11],
+           (int)r[13], (int)r[14], r2[2]);
     lrd_session_close(s);
     return 0;
 }

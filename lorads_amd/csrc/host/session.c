@@ -160,8 +160,26 @@ int lrd_session_admm_steps(lrd_session *s, int steps, double rho, double io[4]) 
     return 0;
 }
 
+/* DIMACS error 2 of the current multipliers (-1 when the table lacks the slot) */
+int lrd_session_dual_infeasibility(lrd_session *s, double *err_dual_l1) {
+    if (!s->have_sol) return 1;
+    int rc = lrd_dual_infeasibility(&s->sol);
+    *err_dual_l1 = s->sol.err_dual_l1;
+    return rc;
+}
+
 /* results: [pObj, dObj, constrVio(1), pdGap, alm_outer, alm_inner, alm_rho, admm_iter, cg_iter, admm_rho,
- *           t_alm, t_admm, status, admm_iters_first, cg_iters_first, constrVio(Inf)] */
+ *           t_alm, t_admm, status, admm_iters_first, cg_iters_first, constrVio(Inf)];
+ * lrd_session_results2 appends [dualInfeas(1), dualInfeas(Inf), t_dual_infeas, scaleObjHis] */
+int lrd_session_results2(lrd_session *s, double out[4]) {
+    if (!s->have_sol) return 1;
+    lrd_solver *v = &s->sol;
+    out[0] = v->err_dual_l1;
+    out[1] = v->err_dual_l1 < 0 ? -1.0 : v->err_dual_l1 * (1 + s->prob->cObjNrm1) / (1 + s->prob->cObjNrmInf);
+    out[2] = v->t_dual_infeas;
+    out[3] = v->scaleObjHis;
+    return 0;
+}
 int lrd_session_results(lrd_session *s, double out[16]) {
     if (!s->have_sol) return 1;
     lrd_solver *v = &s->sol;

@@ -539,11 +539,36 @@ double lrd_reopt(lrd_params *par, lrd_solver *s, double reopt_param, int reopt_a
     return t1 - t0;
 }
 
-/* main.c:321-398 + status classification :478-487 (without the dual-infeasibility term) */
+/* calculate_dual_infeasibility_solver (data/lorads_solver.c:1007-1037): the table's optional slot returns
+ * sum_k |min(lambda_min(C_k - A_k^*(lambda)), 0)| over the cones it holds; ranks add theirs; then the two
+ * divisions of :1034-1035.  Copies the value into the ADMM state like main.c:404-409. */
+int lrd_dual_infeasibility(lrd_solver *s) {
+    if (!s->be->dual_infeasibility) { s->err_dual_l1 = -1.0; return 1; }
+    double t = lrd_time(), v = 0.0;
+    if (s->be->dual_infeasibility(s->be->ctx, &v)) { s->err_dual_l1 = -1.0; return 1; }
+    if (s->allreduce) s->allreduce(s->allreduce_user, &v, 1, 0);
+    s->err_dual_l1 = v / s->scaleObjHis / (s->prob->cObjNrm1 + 1);
+    lrd_admm_state *d = &s->admm;
+    d->l_1_dual_infeasibility = s->err_dual_l1;
+    d->l_inf_dual_infeasibility = s->err_dual_l1 * (1 + s->prob->cObjNrm1) / (1 + s->prob->cObjNrmInf);
+    d->l_2_dual_infeasibility = s->err_dual_l1 * (1 + s->prob->cObjNrm1) / (1 + s->prob->cObjNrm2);
+    d->primal_dual_gap = s->err_pdgap;
+    d->l_1_primal_infeasibility = s->err_constr_l1;
+    d->l_inf_primal_infeasibility = inf_from_l1(s, s->err_constr_l1);
+    d->l_2_primal_infeasibility = l2_from_l1(s, s->err_constr_l1);
+    s->t_dual_infeas += lrd_time() - t;
+    return 0;
+}
+
+/* main.c:321-476 + status classification :478-487.  A table without the dual_infeasibility slot stops after
+ * the level-1 round and classifies without the dual term (err_dual_l1 stays -1; that is also what
+ * oracle/ref_driver.c does with the reference, whose ARPACK dependency cannot be linked here). */
 int lrd_solve(lrd_params *par, lrd_solver *s) {
     double t0 = lrd_time();
     int bad = 0;
     s->status = LRD_UNKNOWN;
+    s->err_dual_l1 = -1.0;
+    s->t_dual_infeas = 0.0;
     double ta = lrd_time();
     lrd_alm_optimize(par, s, 0, 0, par->ALMRhoFactor, t0);
     s->t_alm = lrd_time() - ta;
@@ -554,16 +579,49 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
     s->t_admm = lrd_time() - ta;
     s->admm_iters_first = s->admm.iter;
     s->cg_iters_first = s->cgIter;
+    const int admm_reopt_min_iter = par->highAccMode ? 1000 : 50;
     int cnt = 0;
     if (par->reoptLevel >= 1) {
         while ((s->alm.primal_dual_gap > par->phase2Tol || s->alm.l_1_primal_infeasibility > par->phase2Tol) &&
                (s->admm.primal_dual_gap > par->phase2Tol || s->admm.l_1_primal_infeasibility > par->phase2Tol)) {
             if (cnt >= 1) break;
             if (par->verbose) printf("******  reopt parameter:%.3f\n", 5.0);
-            lrd_reopt(par, s, 5.0, 3, par->highAccMode ? 1000 : 50, t0, &bad, 1);
+            lrd_reopt(par, s, 5.0, 3, admm_reopt_min_iter, t0, &bad, 1);
             cnt += 1;
             if (lrd_time() - t0 > par->timeSecLimit) { s->status = LRD_TIME_LIMIT; return 0; }
         }
+    }
+    const int have_dual = lrd_dual_infeasibility(s) == 0; /* main.c:400-413, evaluated at every reoptLevel */
+    if (have_dual) {
+        lrd_admm_state *d = &s->admm;
+        if (par->verbose)
+            printf("Dual infeasibility: l_1 = %f, l_inf = %f, l_2 = %f\n", d->l_1_dual_infeasibility, d->l_inf_dual_infeasibility,
+                   d->l_2_dual_infeasibility);
+        int dual_cnt = 0; /* main.c:414-476 */
+        while (par->reoptLevel >= 2 && (d->l_1_dual_infeasibility > par->phase2Tol || d->primal_dual_gap > par->phase2Tol ||
+                                        d->l_1_primal_infeasibility > par->phase2Tol)) {
+            if (dual_cnt >= 2) break;
+            if (!par->highAccMode && d->l_1_dual_infeasibility <= 5 * par->phase2Tol && d->primal_dual_gap <= 5 * par->phase2Tol &&
+                d->l_1_primal_infeasibility <= par->phase2Tol)
+                break;
+            if (par->verbose) printf("******  reopt parameter:%.3f\n", 5.0);
+            lrd_reopt(par, s, 5.0, 3, 50, t0, &bad, 2);
+            s->be->average_uv_to_v(s->be->ctx); /* averageUV + copyRtoV, main.c:438-448 */
+            if (lrd_dual_infeasibility(s)) break;
+            if (par->verbose)
+                printf("reopt %d:Dual infeasibility: l_1 = %f, l_inf = %f, l_2 = %f\n", dual_cnt, d->l_1_dual_infeasibility,
+                       d->l_inf_dual_infeasibility, d->l_2_dual_infeasibility);
+            dual_cnt += 1;
+            if (lrd_time() - t0 > par->timeSecLimit) { s->status = LRD_TIME_LIMIT; return 0; }
+        }
+        if (d->l_1_dual_infeasibility <= 5 * par->phase2Tol && d->primal_dual_gap <= 5 * par->phase2Tol &&
+            d->l_1_primal_infeasibility <= par->phase2Tol)
+            s->status = LRD_PRIMAL_DUAL_OPTIMAL;
+        else if (d->primal_dual_gap <= 5 * par->phase2Tol && d->l_1_primal_infeasibility <= par->phase2Tol)
+            s->status = LRD_PRIMAL_OPTIMAL;
+        else
+            s->status = LRD_MAXITER;
+        return 0;
     }
     if (s->err_pdgap <= 5 * par->phase2Tol && s->err_constr_l1 <= par->phase2Tol) s->status = LRD_PRIMAL_OPTIMAL;
     else s->status = LRD_MAXITER;

@@ -54,6 +54,7 @@ class BackendStruct(C.Structure):
         ("set_allreduce", C.CFUNCTYPE(C.c_int, C.c_void_p, ALLREDUCE_FN, C.c_void_p)),
         ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
         ("admm_step", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, _dp)),
+        ("dual_infeasibility", C.CFUNCTYPE(C.c_int, C.c_void_p, _dp)),
     ]
 
 
@@ -136,6 +137,16 @@ class Backend:
         _check(self._s.cal_dual_obj(self._s.ctx, C.byref(v)), "cal_dual_obj")
         return v.value
 
+    @property
+    def has_dual_infeasibility(self):
+        return bool(self._s.dual_infeasibility)
+
+    def dual_infeasibility(self):
+        """sum over the table's cones of |min(lambda_min(C_k - A_k^*(lambda)), 0)| (optional slot)"""
+        v = C.c_double()
+        _check(self._s.dual_infeasibility(self._s.ctx, C.byref(v)), "dual_infeasibility")
+        return v.value
+
     def alm_to_admm(self):
         _check(self._s.alm_to_admm(self._s.ctx), "alm_to_admm")
 
@@ -190,6 +201,8 @@ def _bind(lib):
     lib.lrd_session_alm_to_admm.restype = None
     lib.lrd_session_admm.argtypes = [C.c_void_p, C.c_int]
     lib.lrd_session_results.argtypes = [C.c_void_p, _dp]
+    lib.lrd_session_results2.argtypes = [C.c_void_p, _dp]
+    lib.lrd_session_dual_infeasibility.argtypes = [C.c_void_p, _dp]
     lib.lrd_session_block_info.argtypes = [C.c_void_p, C.c_int] + [_ip] * 8
     lib.lrd_session_dims.argtypes = [C.c_void_p, _ip, _ip, _ip]
     lib.lrd_session_start.restype = _dp
@@ -332,6 +345,15 @@ class Session:
         _check(lib.lorads_hip_algorithmic_bytes(ctx, blk, C.byref(a), C.byref(b)), "algorithmic_bytes")
         return a.value, b.value
 
+    def hip_dual_infeasibility(self, tol=1e-2, ncv=40, max_restarts=600):
+        """(sum_k |min(lambda_min_k, 0)|, per-cone lambda_min, S x products) straight from the C ABI"""
+        lib, ctx = self._hip()
+        lib.lorads_hip_dual_infeasibility.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, _dp, _dp, _ip]
+        nb = self.nblk
+        v, lm, mv = C.c_double(), (C.c_double * max(nb, 1))(), C.c_int()
+        _check(lib.lorads_hip_dual_infeasibility(ctx, tol, ncv, max_restarts, C.byref(v), lm, C.byref(mv)), "dual_infeasibility")
+        return v.value, [lm[i] for i in range(nb)], mv.value
+
     def hip_stream(self):
         """hipStream_t of the library as an integer (torch.cuda.ExternalStream takes it)"""
         lib, ctx = self._hip()
@@ -390,7 +412,17 @@ class Session:
     def results(self):
         out = (C.c_double * 16)()
         _check(self.lib.lrd_session_results(self.h, out), "results")
-        return dict(zip(RESULT_KEYS, [out[i] for i in range(16)]))
+        res = dict(zip(RESULT_KEYS, [out[i] for i in range(16)]))
+        o2 = (C.c_double * 4)()
+        _check(self.lib.lrd_session_results2(self.h, o2), "results2")
+        res.update(dual_infeas_l1=o2[0], dual_infeas_inf=o2[1], t_dual_infeas=o2[2], scale_obj_his=o2[3])
+        return res
+
+    def dual_infeasibility(self):
+        """DIMACS error 2 of the current multipliers, data/lorads_solver.c:1007-1037 (-1: slot missing)"""
+        v = C.c_double()
+        self.lib.lrd_session_dual_infeasibility(self.h, C.byref(v))
+        return v.value
 
     def close(self):
         if self.h:

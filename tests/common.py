@@ -192,3 +192,34 @@ def replay_trace(sess, g, rtol=1e-9, atol=1e-13, resync=True):
             l1 = float(sc[2])
             cg_total = int(sc[4])
     return log
+
+
+def slack_matrices(prob, lam):
+    """S_k = C_k - sum_i lam_i A_ik per cone as scipy CSR, straight from the generator's SDPA entries
+    (C = -F0, the sign the reference stores; data/lorads_solver.c:1027-1029)."""
+    import scipy.sparse as sp
+    out = []
+    for k, n in enumerate(prob["blocks"]):
+        rows, cols, vals = [], [], []
+        for mat, blk, i, j, v in prob["entries"]:
+            if blk - 1 != k:
+                continue
+            w = -v if mat == 0 else -lam[mat - 1] * v
+            rows.append(i - 1), cols.append(j - 1), vals.append(w)
+            if i != j:
+                rows.append(j - 1), cols.append(i - 1), vals.append(w)
+        out.append(sp.csr_matrix((vals, (rows, cols)), shape=(n, n)))
+    return out
+
+
+def c_norm1(prob):
+    """sum of |C_ij| over the full symmetric matrix (LORADSNrm1Obj, data/lorads_solver.c)"""
+    t = 0.0
+    acc = {}
+    for mat, blk, i, j, v in prob["entries"]:
+        if mat == 0:
+            key = (blk, max(i, j), min(i, j))
+            acc[key] = acc.get(key, 0.0) + v
+    for (blk, i, j), v in acc.items():
+        t += abs(v) * (1 if i == j else 2)
+    return t

@@ -1,0 +1,60 @@
+"""DIMACS error 2/6: lambda_min of the dual slack C - A^*(lambda).
+
+The reference computes it with ARPACK (data/lorads_sdp_conic.c:1286-1349), which cannot be linked in this
+image, so the compiled reference (oracle/_ref) never produced goldens for it.  This row is pinned instead on
+  (1) numpy.linalg.eigvalsh of the same slack matrix, assembled here from the generator's SDPA entries, and
+  (2) scipy.sparse.linalg.eigsh -- ARPACK's dsaupd/dseupd itself -- with the reference's parameters
+      (which="SA", k=1, ncv=40, tol=1e-2, maxiter=600).
+"""
+import numpy as np
+import pytest
+
+from tests import common
+from lorads_amd import host, instances
+
+NAMES = ["maxcut100", "rand120", "blk4x60", "theta30", "densec40", "matcomp60", "coupled3x70"]
+
+
+def _exact(prob, lam):
+    return [float(np.linalg.eigvalsh(S.toarray())[0]) for S in common.slack_matrices(prob, lam)]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_slack_eigenvalue_vs_numpy_and_arpack(name):
+    import scipy.sparse.linalg as sla
+    prob = instances.NAMED[name]()
+    lam = np.random.default_rng(5).standard_normal(prob["m"])
+    with common.oracle_session(common.instance_path(name)) as s:
+        s.be.set_vec(host.VEC_LAMBDA, lam)
+        got = s.be.dual_infeasibility()
+        err = s.dual_infeasibility()
+    ex = _exact(prob, lam)
+    want = sum(abs(min(e, 0.0)) for e in ex)
+    assert got == pytest.approx(want, rel=1e-10, abs=1e-12)
+    # the host's two divisions (data/lorads_solver.c:1034-1035); no reopt happened, scaleObjHis = 1
+    assert err == pytest.approx(want / (1.0 + common.c_norm1(prob)), rel=1e-10)
+    # ARPACK with the reference's own parameters lands within its tolerance of the same number
+    for S, e in zip(common.slack_matrices(prob, lam), ex):
+        n = S.shape[0]
+        ncv = 40 if n >= 40 else n  # dual_infeasible shrinks the subspace for tiny cones (:1290-1294)
+        th = sla.eigsh(S.astype(np.float64), k=1, which="SA", ncv=ncv, tol=1e-2, maxiter=600, return_eigenvectors=False)[0]
+        assert abs(th - e) <= 1e-2 * abs(e)
+
+
+def test_level2_reopt_flow_uses_dual_infeasibility():
+    """matcomp60 leaves phase 2 with dual infeasibility 3.7e-4 > phase2Tol: reoptLevel 2 must run the extra round
+    (main.c:414-476) and end dual feasible; reoptLevel 1 must not."""
+    prob = instances.NAMED["matcomp60"]()
+    res = {}
+    for lvl in (1, 2):
+        with common.oracle_session(common.instance_path("matcomp60"), reoptLevel=lvl, phase1Tol=1e-2) as s:
+            s.solve()
+            res[lvl] = s.results()
+            lam = s.be.get_vec(host.VEC_LAMBDA)
+        # the reported number is the eigenvalue of the slack at the final (scaled) multipliers
+        ex = _exact(prob, lam / res[lvl]["scale_obj_his"])
+        want = sum(abs(min(e, 0.0)) for e in ex) / (1.0 + common.c_norm1(prob))
+        assert res[lvl]["dual_infeas_l1"] == pytest.approx(want, rel=1e-6, abs=1e-12)
+    assert res[1]["dual_infeas_l1"] > 1e-5 and res[1]["scale_obj_his"] == 1.0
+    assert res[2]["dual_infeas_l1"] <= 5e-5 and res[2]["scale_obj_his"] == 5.0
+    assert res[2]["status"] in (1.0, 2.0)

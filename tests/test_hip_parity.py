@@ -227,3 +227,77 @@ def test_cg_long_solve_with_restarts(built):
     finally:
         hs.close()
         os_.close()
+
+
+# ---------------------------------------------------------------- dual infeasibility
+def _exact_min_eigs(prob, lam):
+    return [float(np.linalg.eigvalsh(S.toarray())[0]) for S in common.slack_matrices(prob, lam)]
+
+
+@pytest.mark.parametrize("name", TRACE_NAMES + ["densec300"])
+def test_dual_infeasibility_vs_oracle_and_numpy(built, name):
+    """lambda_min(C - A^*(lambda)) from the device Lanczos against numpy's dense eigensolver (exact) and the
+    oracle slot, for arbitrary multipliers (indefinite slack).  Driven to 1e-10 it must agree to 1e-8; with
+    the reference's ARPACK tolerance (1e-2) it must sit within that tolerance ABOVE the exact value (a Ritz
+    value never undershoots)."""
+    from lorads_amd import instances
+    prob = instances.NAMED[name]()
+    path = common.instance_path(name) if name != "densec300" else _gen(name)
+    lam = np.random.default_rng(5).standard_normal(prob["m"])
+    ex = _exact_min_eigs(prob, lam)
+    want = sum(abs(min(e, 0.0)) for e in ex)
+    hs, os_ = _pair(path)
+    try:
+        for s in (hs, os_):
+            s.be.set_vec(host.VEC_LAMBDA, lam)
+        tight, lam_min, _ = hs.hip_dual_infeasibility(tol=1e-10)
+        assert np.allclose(lam_min, ex, rtol=1e-8, atol=1e-10)
+        assert tight == pytest.approx(want, rel=1e-8)
+        loose, lam_min2, nmv = hs.hip_dual_infeasibility()  # tol 1e-2, ncv 40, 600 restarts
+        for a, e in zip(lam_min2, ex):
+            assert e - 1e-9 * abs(e) <= a <= e + 1e-2 * abs(e)
+        assert hs.be.dual_infeasibility() == pytest.approx(loose, rel=1e-12)
+        assert os_.be.dual_infeasibility() == pytest.approx(tight, rel=1e-8)
+        # through the host: the two divisions of data/lorads_solver.c:1034-1035
+        assert hs.dual_infeasibility() == pytest.approx(loose / (1.0 + common.c_norm1(prob)), rel=1e-12)
+    finally:
+        hs.close(), os_.close()
+
+
+@pytest.mark.parametrize("name,tlr", [("maxcut4000", 3.0), ("rand4000", 3.0), ("maxcut20000", 4.0), ("rand20000", 4.0)])
+def test_dual_infeasibility_large_vs_arpack(built, name, tlr):
+    """mid and BASELINE-size cones against ARPACK itself (scipy eigsh = dsaupd/dseupd) run to 1e-10 on the
+    same slack matrix; the device result at the reference's tolerance must be within that tolerance, and the
+    tight one equal to 1e-7."""
+    import scipy.sparse.linalg as sla
+    from lorads_amd import instances
+    prob = instances.NAMED[name]()
+    lam = np.random.default_rng(7).standard_normal(prob["m"])
+    S = common.slack_matrices(prob, lam)[0]
+    ref = float(sla.eigsh(S, k=1, which="SA", ncv=60, tol=1e-10, return_eigenvectors=False)[0])
+    hs = common.hip_session(_gen(name), timesLogRank=tlr)
+    try:
+        hs.be.set_vec(host.VEC_LAMBDA, lam)
+        _, lm_tight, nmv_t = hs.hip_dual_infeasibility(tol=1e-9)
+        _, lm_loose, nmv_l = hs.hip_dual_infeasibility()
+        assert lm_tight[0] == pytest.approx(ref, rel=1e-7)
+        assert ref - 1e-9 * abs(ref) <= lm_loose[0] <= ref + 1e-2 * abs(ref)
+        assert nmv_l <= nmv_t
+    finally:
+        hs.close()
+
+
+def test_whole_solve_level2_hip_vs_oracle(built):
+    """reoptLevel 2 (main.c:414-476): matcomp60 leaves phase 2 dual infeasible, so the extra round must run on
+    both tables; both must end dual feasible with matching objectives."""
+    res = []
+    for mk in (common.hip_session, common.oracle_session):
+        with mk(common.instance_path("matcomp60"), reoptLevel=2, phase1Tol=1e-2) as s:
+            s.solve()
+            res.append(s.results())
+    h, o = res
+    assert h["scale_obj_his"] == o["scale_obj_his"] == 5.0
+    assert 0.0 <= h["dual_infeas_l1"] <= 5e-5 and 0.0 <= o["dual_infeas_l1"] <= 5e-5
+    assert h["pObj"] == pytest.approx(o["pObj"], rel=1e-4)
+    assert h["dObj"] == pytest.approx(o["dObj"], rel=1e-4)
+    assert h["status"] == o["status"]
