@@ -92,6 +92,16 @@ int lorads_hip_update_dimacs(lorads_hip_ctx *ctx, int32_t pair, double *err1);
 /* lorads_func.calObj_alm / calObj_admm (lorads_alm.c:1259-1268, lorads_admm.c:325-337): <C, R R^T>
  * summed over this context's cones (pair UV: after R = (U+V)/2); not divided by scaleObjHis */
 int lorads_hip_cal_obj(lorads_hip_ctx *ctx, int32_t pair, double *pobj);
+/* Fused phase-1 inner iteration (optional; the slot-by-slot calls above give identical results).  The body of
+ * the reference's inner loop (lorads_alm.c:1066-1131) is  [direction, q12p12, line-search sums] -> scalar cubic
+ * on the host -> [setAsNegGrad, ALMupdateVar(tau), ALMCalGrad, setlbfgsHisTwo, updateDimacsALM].
+ *   alm_front: first bracket for inner-iteration counter `inner`; out = {p1, p2, a, b, c, d}
+ *   alm_step : second bracket with the host's tau, then (next_inner >= 0) the first bracket of the NEXT iteration,
+ *              enqueued back to back with ONE host synchronisation;
+ *              out = {lagNormSq, err1, p1, p2, a, b, c, d} (p, a..d belong to the next iteration)
+ * If the host leaves the loop instead, the pre-computed direction is discarded (it lives in D = U, q1, q2). */
+int lorads_hip_alm_front(lorads_hip_ctx *ctx, double rho, int32_t inner, double out[6]);
+int lorads_hip_alm_step(lorads_hip_ctx *ctx, double rho, double tau, int32_t next_inner, double out[8]);
 /* lorads_func.admmUpdateVar = LORADSUpdateSDPVar (lorads_alg_common.c:187-215) with
  * LORADSUpdateSDPVarOne (lorads_admm.c:428-480) and CGSolve (linalg/lorads_cgs.c:81-240);
  * *cg_iters = sum of the CG iteration counts the reference would add to ASolver->cgIter */

@@ -628,6 +628,7 @@ __global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const do
                                                     const double *__restrict__ q1, const double *__restrict__ q2,
                                                     double *__restrict__ out) {
     __shared__ double sh[4];
+    if (threadIdx.x == 0) { out[5] = q1[2 * (size_t)m]; out[6] = q1[2 * (size_t)m + 1]; } // p1, p2 ride along (q12 layout)
     double s[5] = {0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < m; i += TPB) {
         const double q0 = (b[i] - csum[i]) + rinv * lambda[i];
@@ -1280,7 +1281,7 @@ int first_unfinished(lorads_hip_ctx *c, int first) {
 
 // objective + DIMACS refresh (calObj_admm + LORADSCalDualObj + updateDimacsADMM, lorads_admm.c:79-81):
 // R = (U+V)/2 (pair UV), constrVal <- A(R R^T), constrValSum, then scal[0..2] = {||b-sum||^2, b.lambda, <C,RR^T>}
-int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need) {
+int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = true) {
     const Guard g{nullptr, need};
     if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, g);
     const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
@@ -1290,11 +1291,12 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need) {
     int nobj = 0;
     for (auto &B : c->blk) {
         constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
+        if (!with_obj) continue; // DIMACS refresh alone (lorads_alg_common.c:250-290) does not touch the objective
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
         if (fold_obj) { nobj = go; continue; }
         if (go) { LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, first_obj ? 0 : 1, c->scal + 2, g); first_obj = false; }
     }
-    if (first_obj && !(fold_obj && nobj > 0)) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
+    if (with_obj && first_obj && !(fold_obj && nobj > 0)) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
     if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part] per evaluation
         HC(hipMemcpyAsync(c->csum + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
@@ -1454,7 +1456,7 @@ int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
     return allreduce_dev(c, c->csum, c->m);
 }
 
-int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
+static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
     LAUNCH(k_zero, 1, (size_t)1, c->scal + 8, NOGUARD);
     for (auto &B : c->blk) {
         WArgs wa{};
@@ -1465,7 +1467,10 @@ int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
                      B.dense_c ? B.Wd : nullptr);
         LAUNCH(k_finalize, 1, part_slot(c, 0), g, 1.0, 1, c->scal + 8, NOGUARD);
     }
-    if (allreduce_dev(c, c->scal + 8, 1)) return 1;
+    return allreduce_dev(c, c->scal + 8, 1);
+}
+int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
+    if (enqueue_alm_grad(c, rho)) return 1;
     return read_scalars(c, 8, 1, lag);
 }
 
@@ -1504,7 +1509,7 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     return 0;
 }
 
-int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
+static int enqueue_q12p12(lorads_hip_ctx *c) {
     const int m = c->m;
     LAUNCH(k_zero, grid1d((size_t)2 * m + 2), (size_t)2 * m + 2, c->q12, NOGUARD);
     for (int pass = 0; pass < 2; ++pass) {
@@ -1516,18 +1521,25 @@ int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
             if (g) LAUNCH(k_finalize, 1, part_slot(c, 4), g, scale, 1, c->q12 + 2 * m + pass, NOGUARD);
         }
     }
-    if (allreduce_dev(c, c->q12, 2 * m + 2)) return 1;
-    return read_scalars_at(c, c->q12 + 2 * m, 2, p12);
+    return allreduce_dev(c, c->q12, 2 * m + 2);
+}
+int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
+    if (enqueue_q12p12(c)) return 1;
+    return read_scalars_at(c, c->q12 + 2 * c->m, 2, p12);
 }
 
-int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
-    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
-    double s[5];
-    if (read_scalars(c, 16, 5, s)) return 1;
+// quartic coefficients of the line search from the five m-vector sums (lorads_alm.c:164-172)
+static void quartic_coeffs(double rho, double p1, double p2, const double s[5], double k[4]) {
     k[0] = rho * s[0] / 2;              // rho ||q2||^2 / 2
     k[1] = rho * s[1];                  // rho q1.q2
     k[2] = p2 - rho * s[3] + rho * s[2] / 2;
     k[3] = p1 - rho * s[4];
+}
+int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
+    double s[5];
+    if (read_scalars(c, 16, 5, s)) return 1;
+    quartic_coeffs(rho, p1, p2, s, k);
     return 0;
 }
 
@@ -1552,8 +1564,42 @@ int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
     return 0;
 }
 
+// Fused phase-1 inner iteration (a16-a19).  The reference's inner loop body is
+//   direction, q12p12, line search | setAsNegGrad, ALMupdateVar(tau), ALMCalGrad, setlbfgsHisTwo, updateDimacsALM
+// (lorads_alm.c:1066-1131) with the scalar line search in the middle.  alm_front enqueues the first half and reads
+// {p1, p2, a, b, c, d}; alm_step takes tau, enqueues the second half AND -- speculatively -- the first half of the
+// next iteration, and reads everything with ONE host synchronisation: out = {lagNormSq, err1, p1, p2, a, b, c, d}.
+// Same kernels in the same order as the slot-by-slot calls, so the results are identical; if the host leaves the
+// loop, the speculated direction is simply never used (it only touched D, q1/q2 and scratch).
+static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner) {
+    if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c)) return 1;
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
+    return 0;
+}
+int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double out[6]) {
+    if (enqueue_alm_front(c, rho, inner)) return 1;
+    double s[7];
+    if (read_scalars(c, 16, 7, s)) return 1;
+    out[0] = s[5]; out[1] = s[6];
+    quartic_coeffs(rho, s[5], s[6], s, out + 2);
+    return 0;
+}
+int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
+    if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
+        lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false))
+        return 1;
+    if (next_inner >= 0 && enqueue_alm_front(c, rho, next_inner)) return 1;
+    double s[23];
+    if (read_scalars(c, 0, 23, s)) return 1;
+    out[0] = s[8];
+    out[1] = std::sqrt(s[0]) / (1 + c->b_nrm1);
+    out[2] = s[21]; out[3] = s[22];
+    if (next_inner >= 0) quartic_coeffs(rho, s[21], s[22], s + 16, out + 4);
+    return 0;
+}
+
 int lorads_hip_update_dimacs(lorads_hip_ctx *c, int32_t pair, double *err1) {
-    if (enqueue_eval(c, pair, nullptr)) return 1;
+    if (enqueue_eval(c, pair, nullptr, false)) return 1;
     double s[3];
     if (read_scalars(c, 0, 3, s)) return 1;
     *err1 = std::sqrt(s[0]) / (1 + c->b_nrm1);

@@ -43,6 +43,8 @@ typedef struct {
     int (*set_allreduce)(lorads_hip_ctx *, lorads_hip_allreduce_fn, void *);
     int (*admm_step)(lorads_hip_ctx *, double, double, int32_t, double *);
     int (*dual_infeasibility)(lorads_hip_ctx *, double, int32_t, int32_t, double *, double *, int32_t *);
+    int (*alm_front)(lorads_hip_ctx *, double, int32_t, double *);
+    int (*alm_step)(lorads_hip_ctx *, double, double, int32_t, double *);
 } hipbe;
 
 #define H ((hipbe *)cx)
@@ -70,6 +72,8 @@ static int b_admm(void *cx, double rho, double tol, int mx, int *it) {
 }
 static int b_step(void *cx, double rho, double tol, int mx, double o[4]) { return report(H, H->admm_step(H->ctx, rho, tol, mx, o), "admm_step"); }
 /* ARPACK parameters of dual_infeasible (data/lorads_sdp_conic.c:1288-1319): tol 1e-2, ncv 40, 600 restarts */
+static int b_afront(void *cx, double rho, int inner, double o[6]) { return report(H, H->alm_front(H->ctx, rho, inner, o), "alm_front"); }
+static int b_astep(void *cx, double rho, double tau, int nx, double o[8]) { return report(H, H->alm_step(H->ctx, rho, tau, nx, o), "alm_step"); }
 static int b_dinf(void *cx, double *v) { return report(H, H->dual_infeasibility(H->ctx, 1e-2, 40, 600, v, NULL, NULL), "dual_infeasibility"); }
 static int b_dual(void *cx, double rho) { return report(H, H->update_dual_var(H->ctx, rho), "update_dual_var"); }
 static int b_dobj(void *cx, double *v) { return report(H, H->cal_dual_obj(H->ctx, v), "cal_dual_obj"); }
@@ -125,7 +129,7 @@ int lrd_hip_backend_create(const lrd_problem *p, int lbfgs_len, const char *libp
     SYM(cal_dual_obj, "cal_dual_obj"); SYM(alm_to_admm, "alm_to_admm"); SYM(average_uv_to_v, "average_uv_to_v");
     SYM(scale_obj, "scale_obj"); SYM(resize_rank, "resize_rank"); SYM(set_mat, "set_mat"); SYM(get_mat, "get_mat");
     SYM(set_vec, "set_vec"); SYM(get_vec, "get_vec"); SYM(set_allreduce, "set_allreduce"); SYM(admm_step, "admm_step");
-    SYM(dual_infeasibility, "dual_infeasibility");
+    SYM(dual_infeasibility, "dual_infeasibility"); SYM(alm_front, "alm_front"); SYM(alm_step, "alm_step");
 #undef SYM
     lorads_hip_block *hb = (lorads_hip_block *)calloc((size_t)(p->nblk > 0 ? p->nblk : 1), sizeof *hb);
     for (int k = 0; k < p->nblk; ++k) {
@@ -157,5 +161,7 @@ int lrd_hip_backend_create(const lrd_problem *p, int lbfgs_len, const char *libp
     out->destroy = b_destroy;
     out->admm_step = b_step;
     out->dual_infeasibility = b_dinf;
+    out->alm_front = b_afront;
+    out->alm_step = b_astep;
     return 0;
 }

@@ -139,6 +139,13 @@ typedef struct lrd_backend {
     /* OPTIONAL (may be NULL): calculate_dual_infeasibility_solver without its two divisions
      * (data/lorads_solver.c:1007-1033): sum over this table's cones of |min(lambda_min(C_k - A_k^*(lambda)), 0)| */
     int (*dual_infeasibility)(void *ctx, double *sum_neg_eig);
+    /* OPTIONAL pair (both or neither): the phase-1 inner iteration in two calls with one host round trip each
+     * (lorads_alm.c:1066-1131).  alm_front = lbfgs_direction(inner) + alm_q12p12 + alm_linesearch_coeffs,
+     * out = {p1, p2, a, b, c, d};  alm_step = set_y_as_neg_grad + alm_update_var(tau) + alm_cal_grad(rho) +
+     * set_lbfgs_his_two(tau) + update_dimacs(RR), then alm_front(next_inner) when next_inner >= 0,
+     * out = {lagNormSq, err1, p1, p2, a, b, c, d}.  Same results as the separate slots. */
+    int (*alm_front)(void *ctx, double rho, int inner, double out[6]);
+    int (*alm_step)(void *ctx, double rho, double tau, int next_inner, double out[8]);
 } lrd_backend;
 
 /* iteration states, as the reference's lorads_alm_state / lorads_admm_state

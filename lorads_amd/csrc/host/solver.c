@@ -266,13 +266,24 @@ restart:
             if (cur_iter_counter >= s->max_alm_sub_iter) { sub_counter += 1; break; }
             if (rank_flag >= rank_thres && !is_rank_max && (k - last_outer_start >= 3)) break;
             if (cert_val <= cert_tol) break;
+            /* fused path: the table offers the inner iteration as two calls with one host round trip each and
+             * pre-computes the next direction while the host looks at this one's results */
+            const int fused = be->alm_step && be->alm_front && s->use_fused_step && !s->allreduce;
+            int have_front = 0;
+            double front[6] = {0, 0, 0, 0, 0, 0};
             while (cert_val - cert_tol > par->endALMSubTol) {
                 /* L-BFGS memory reset every 300 steps: `localIter % 300` vs `(localIter-1) % 300` */
                 if ((!reopt && local_iter % 300 == 0) || (reopt && (local_iter - 1) % 300 == 0)) clear_lbfgs = 0;
-                be->lbfgs_direction(cx, clear_lbfgs);
                 double p12[2], coef[4];
-                be->alm_q12p12(cx, p12);
-                be->alm_linesearch_coeffs(cx, st->rho, p12[0], p12[1], coef);
+                if (!fused) {
+                    be->lbfgs_direction(cx, clear_lbfgs);
+                    be->alm_q12p12(cx, p12);
+                    be->alm_linesearch_coeffs(cx, st->rho, p12[0], p12[1], coef);
+                } else {
+                    if (!have_front && be->alm_front(cx, st->rho, clear_lbfgs, front)) { ret = LRD_RET_NUM_ERR; goto end_alm; }
+                    memcpy(coef, front + 2, sizeof coef);
+                    have_front = 0;
+                }
                 int nroot = lrd_linesearch_tau(coef, &tau);
                 if (nroot == 0) { ret = LRD_RET_NUM_ERR; goto end_alm; }
                 if (fabs(tau) < par->endTauTol) {
@@ -281,11 +292,23 @@ restart:
                     jump_update_rho = 1;
                     break;
                 }
-                be->set_y_as_neg_grad(cx);
-                be->alm_update_var(cx, tau);
-                be->alm_cal_grad(cx, st->rho, &lag);
-                be->set_lbfgs_his_two(cx, tau);
-                be->update_dimacs(cx, LRD_PAIR_RR, &s->err_constr_l1);
+                if (!fused) {
+                    be->set_y_as_neg_grad(cx);
+                    be->alm_update_var(cx, tau);
+                    be->alm_cal_grad(cx, st->rho, &lag);
+                    be->set_lbfgs_his_two(cx, tau);
+                    be->update_dimacs(cx, LRD_PAIR_RR, &s->err_constr_l1);
+                } else {
+                    /* the counter the next pass of this loop would hand to lbfgs_direction */
+                    int next_clear = clear_lbfgs + 1;
+                    if ((!reopt && (local_iter + 1) % 300 == 0) || (reopt && local_iter % 300 == 0)) next_clear = 0;
+                    double o[8];
+                    if (be->alm_step(cx, st->rho, tau, next_clear, o)) { ret = LRD_RET_NUM_ERR; goto end_alm; }
+                    lag = o[0];
+                    s->err_constr_l1 = o[1];
+                    memcpy(front, o + 2, sizeof front);
+                    have_front = 1;
+                }
                 { double gap = s->pObjVal - s->dObjVal;
                   s->err_pdgap = fabs(gap) / (1 + fabs(s->pObjVal) + fabs(s->dObjVal)); }
                 st->l_1_primal_infeasibility = s->err_constr_l1;

@@ -55,6 +55,8 @@ class BackendStruct(C.Structure):
         ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
         ("admm_step", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, _dp)),
         ("dual_infeasibility", C.CFUNCTYPE(C.c_int, C.c_void_p, _dp)),
+        ("alm_front", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_int, _dp)),
+        ("alm_step", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, _dp)),
     ]
 
 
@@ -136,6 +138,23 @@ class Backend:
         v = C.c_double()
         _check(self._s.cal_dual_obj(self._s.ctx, C.byref(v)), "cal_dual_obj")
         return v.value
+
+    @property
+    def has_alm_step(self):
+        return bool(self._s.alm_step) and bool(self._s.alm_front)
+
+    def alm_front(self, rho, inner):
+        """(p1, p2, [a, b, c, d]) of the direction for inner-iteration counter `inner` (optional slot)"""
+        o = (C.c_double * 6)()
+        _check(self._s.alm_front(self._s.ctx, rho, inner, o), "alm_front")
+        return o[0], o[1], [o[2], o[3], o[4], o[5]]
+
+    def alm_step(self, rho, tau, next_inner):
+        """finish the inner iteration with step tau and pre-compute the next direction (optional slot):
+        (lagNormSq, err1, p1, p2, [a, b, c, d])"""
+        o = (C.c_double * 8)()
+        _check(self._s.alm_step(self._s.ctx, rho, tau, next_inner, o), "alm_step")
+        return o[0], o[1], o[2], o[3], [o[4], o[5], o[6], o[7]]
 
     @property
     def has_dual_infeasibility(self):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals for the trailing ADMM part of a bench
-run (after the last L-BFGS kernel), busy fraction and gaps.  usage: tools_trace_summary.py trace.csv"""
+run (after the last L-BFGS kernel) or, with `alm` as second argument, for the phase-1 part before it;
+busy fraction and gaps.  usage: trace_summary.py trace.csv [alm]"""
 import collections
 import csv
 import re
@@ -17,10 +18,13 @@ def short(n):
 
 
 last = max(i for i, r in enumerate(rows) if "k_his_two" in r["Kernel_Name"])
-adm = rows[last + 1:]
+alm = len(sys.argv) > 2 and sys.argv[2] == "alm"
+adm = rows[:last + 1] if alm else rows[last + 1:]
+if alm:
+    print("inner iterations (k_his_two launches): %d" % sum(1 for r in adm if "k_his_two" in r["Kernel_Name"]))
 t0 = int(adm[0]["Start_Timestamp"])
 t1 = int(adm[-1]["End_Timestamp"])
-print("ADMM-part kernels: %d  span %.3f ms" % (len(adm), (t1 - t0) / 1e6))
+print(("ALM-part" if alm else "ADMM-part") + " kernels: %d  span %.3f ms" % (len(adm), (t1 - t0) / 1e6))
 agg = collections.OrderedDict()
 for r in adm:
     k = short(r["Kernel_Name"])

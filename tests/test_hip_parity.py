@@ -301,3 +301,58 @@ def test_whole_solve_level2_hip_vs_oracle(built):
     assert h["pObj"] == pytest.approx(o["pObj"], rel=1e-4)
     assert h["dObj"] == pytest.approx(o["dObj"], rel=1e-4)
     assert h["status"] == o["status"]
+
+
+@pytest.mark.parametrize("name,params", [("maxcut100", dict(reoptLevel=0)), ("rand120", dict(reoptLevel=1, phase1Tol=1e-2)),
+                                         ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2)),
+                                         ("theta30", dict(reoptLevel=1, phase1Tol=1e-2))])
+def test_fused_alm_step_equals_separate_calls(built, name, params):
+    """alm_front/alm_step (one host round trip per inner iteration, next direction pre-computed) run the same
+    kernels in the same order as the slot-by-slot path: the whole solve must be identical, iteration counts
+    included."""
+    res = []
+    for fused in (1, 0):
+        with common.hip_session(common.instance_path(name), **params) as s:
+            assert s.be.has_alm_step
+            s.use_fused_step(fused)
+            s.solve()
+            res.append(s.results())
+    a, b = res
+    for k in ("pObj", "dObj", "constrVio1", "pdGap", "alm_outer", "alm_inner", "admm_iter", "cg_iter", "dual_infeas_l1"):
+        assert a[k] == b[k], k
+
+
+def test_alm_front_and_step_function_level(built):
+    """the two fused calls against the seven separate slots on the same state (rand120)"""
+    path = common.instance_path("rand120")
+    out = []
+    for fused in (True, False):
+        with common.hip_session(path) as s:
+            be = s.be
+            rho = 0.7
+            be.init_constr(host.PAIR_RR)
+            be.alm_cal_grad(rho)
+            rec = []
+            front = None
+            for it in range(4):
+                if fused:
+                    p1, p2, coef = front if front is not None else be.alm_front(rho, it)
+                else:
+                    be.lbfgs_direction(it)
+                    p1, p2 = be.alm_q12p12()
+                    coef = be.alm_linesearch_coeffs(rho, p1, p2)
+                tau, _ = common.linesearch_tau(coef)
+                if fused:
+                    lag, err1, np1, np2, ncoef = be.alm_step(rho, tau, it + 1)
+                    front = (np1, np2, ncoef)
+                else:
+                    be.set_y_as_neg_grad()
+                    be.alm_update_var(tau)
+                    lag = be.alm_cal_grad(rho)
+                    be.set_lbfgs_his_two(tau)
+                    err1 = be.update_dimacs(host.PAIR_RR)
+                rec.append([p1, p2, *coef, tau, lag, err1])
+            rec.append(be.get_mat(host.MAT_R, 0).ravel().tolist())
+            out.append(rec)
+    for x, y in zip(*out):
+        assert x == y
