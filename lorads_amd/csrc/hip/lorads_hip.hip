@@ -183,6 +183,92 @@ __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict_
     if (live && act && lane == 0) T[e] = s;
 }
 
+// Both pair dots of the line search from one visit of the four rows (ALMCalq12p12, lorads_alm.c:540-560):
+// t1 = sym-pair(R, D), t2 = sym-pair(D, D), each summed exactly as pair_dot does.
+template <int LG, bool V2, int NS>
+__device__ __forceinline__ void pair_dot_rd(const double *__restrict__ R, const double *__restrict__ D, int p, int q, int r,
+                                            int lane, double &t1, double &t2) {
+    constexpr int W = V2 ? 2 : 1;
+    double rp[NS][W], rq[NS][W], dp[NS][W], dq[NS][W];
+    Slice<LG, V2, NS>::load(R + (size_t)p * r, r, lane, rp);
+    Slice<LG, V2, NS>::load(D + (size_t)q * r, r, lane, dq);
+    Slice<LG, V2, NS>::load(R + (size_t)q * r, r, lane, rq);
+    Slice<LG, V2, NS>::load(D + (size_t)p * r, r, lane, dp);
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            a1 += rp[c][w] * dq[c][w]; a2 += rq[c][w] * dp[c][w];
+            b1 += dp[c][w] * dq[c][w]; b2 += dq[c][w] * dp[c][w];
+        }
+    t1 = p == q ? a1 : a1 + a2;
+    t2 = p == q ? b1 : b1 + b2;
+}
+template <int LG, bool V2, int NS>
+__global__ __launch_bounds__(TPB) void k_pairdots_rd(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
+                                                     const double *__restrict__ R, const double *__restrict__ D, int r,
+                                                     double *__restrict__ T1, double *__restrict__ T2) {
+    const int e = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
+    const bool act = e < ne;
+    const int p = act ? erow[e] : 0, q = act ? ecol[e] : 0;
+    double t1, t2;
+    pair_dot_rd<LG, V2, NS>(R, D, p, q, r, lane, t1, t2);
+    t1 = group_sum<LG>(t1);
+    t2 = group_sum<LG>(t2);
+    if (act && lane == 0) { T1[e] = t1; T2[e] = t2; }
+}
+template <int LG, bool V2, int NS>
+__global__ __launch_bounds__(TPB) void k_obj_rd(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
+                                                const double *__restrict__ cval, const double *__restrict__ R,
+                                                const double *__restrict__ D, int r, double *__restrict__ part1,
+                                                double *__restrict__ part2) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x % LG, per = TPB / LG;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = blockIdx.x * per + threadIdx.x / LG; e < ne; e += gridDim.x * per) {
+        double t1, t2;
+        pair_dot_rd<LG, V2, NS>(R, D, erow[e], ecol[e], r, lane, t1, t2);
+        s1 += t1 * cval[e];
+        s2 += t2 * cval[e];
+    }
+    const double u1 = block_sum(s1, sh), u2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { part1[blockIdx.x] = u1; part2[blockIdx.x] = u2; }
+}
+// q1 = 2 A(T1), q2 = A(T2) for a cone that sees every constraint (vec1/vec2 are SET); cv keeps the second one,
+// as the two successive k_cv passes leave it
+__global__ __launch_bounds__(TPB) void k_cv_rd(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
+                                               const double *__restrict__ a_val, const double *__restrict__ T1,
+                                               const double *__restrict__ T2, double *__restrict__ cv,
+                                               const int *__restrict__ row_idx, double *__restrict__ vec1,
+                                               double *__restrict__ vec2) {
+    const int i = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
+    const bool act = i < nrow;
+    double s1 = 0.0, s2 = 0.0;
+    if (act)
+        for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) {
+            const int e = a_e[t];
+            const double a = a_val[t];
+            s1 += a * T1[e];
+            s2 += a * T2[e];
+        }
+    s1 = group_sum<8>(s1);
+    s2 = group_sum<8>(s2);
+    if (act && lane == 0) {
+        const int gi = row_idx[i];
+        vec1[gi] = s1 * 2.0;
+        vec2[gi] = s2 * 1.0;
+        cv[i] = s2;
+    }
+}
+// out[b] = scale_b * sum(part_b), b = blockIdx.x in {0, 1}
+__global__ __launch_bounds__(TPB) void k_finalize2(const double *__restrict__ part0, const double *__restrict__ part1, int n,
+                                                   double scale0, double scale1, double *out) {
+    __shared__ double sh[4];
+    const double t = sum_partials(blockIdx.x ? part1 : part0, n, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x ? scale1 : scale0) * t;
+}
+
 // partial of sum_e c_e * pairdot_e  (objective <C, sym(X Y^T)>); grid-stride so that the grid stays <= MAXPART
 template <int LG, bool V2, int NS>
 __global__ __launch_bounds__(TPB) void k_obj(int ne, const int *__restrict__ erow, const int *__restrict__ ecol,
@@ -586,6 +672,73 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ par
     const double t = sum_partials(part, n, sh);
     if (live && threadIdx.x == 0) *out = accumulate ? *out + scale * t : scale * t;
 }
+// One stage of the L-BFGS two-loop recursion (lorads_alm.c:230-391) per launch:
+//   [coefficient from the previous stage's dot partials]  ->  q += coef * ax  ->  partials of <dv, q>.
+// Every workgroup re-sums the previous partials in the order k_finalize uses, so all of them see the same
+// coefficient and the arithmetic is that of the k_dot / k_finalize / k_scalar_op / k_axpy_dev chain it replaces.
+// ab = {alpha, beta} of the history node the coefficient belongs to.  dout != nullptr: last stage, D = -q and
+// the partials are those of <D, dv> (dv = Grad).
+enum { ST_FIRST = 0, ST_ALPHA = 1, ST_W = 2 };
+__global__ __launch_bounds__(TPB) void k_lbfgs_stage(size_t len, int op, const double *__restrict__ prev_part, int nprev,
+                                                     double *ab, const double *__restrict__ ax, double *q,
+                                                     const double *__restrict__ qsrc, const double *__restrict__ dv,
+                                                     double *__restrict__ part_out, double *__restrict__ dout) {
+    __shared__ double sh[4];
+    double coef = 0.0;
+    if (op != ST_FIRST) {
+        const double dot = sum_partials(prev_part, nprev, sh);
+        if (op == ST_ALPHA) {
+            const double alpha = ab[1] * dot;
+            coef = -1 * alpha;
+            if (blockIdx.x == 0 && threadIdx.x == 0) ab[0] = alpha;
+        } else {
+            coef = ab[0] - ab[1] * dot;
+        }
+    }
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
+        const double v = op == ST_FIRST ? qsrc[i] : q[i] + coef * ax[i];
+        if (dout) {
+            const double d = -1.0 * v;
+            dout[i] = d;
+            local += d * dv[i];
+        } else {
+            q[i] = v;
+            local += dv[i] * v;
+        }
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = t;
+}
+// D = -G when <D,G> >= 0 (LBFGSDirectionUseGrad), <D,G> given as partials
+__global__ __launch_bounds__(TPB) void k_use_grad_p(size_t len, const double *__restrict__ part, int npart,
+                                                    const double *__restrict__ G, double *__restrict__ D) {
+    __shared__ double sh[4];
+    const double ip = sum_partials(part, npart, sh);
+    if (!(ip >= 0)) return;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) D[i] = -G[i];
+}
+// s = tau*D, y += G (setlbfgsHisTwo) and the partials of <y, s>
+__global__ __launch_bounds__(TPB) void k_his_two_dot(size_t len, double tau, const double *__restrict__ D,
+                                                     const double *__restrict__ G, double *__restrict__ s,
+                                                     double *__restrict__ y, double *__restrict__ part) {
+    __shared__ double sh[4];
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
+        const double si = tau * D[i], yi = y[i] + G[i];
+        s[i] = si;
+        y[i] = yi;
+        local += yi * si;
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// beta = 1 / sum(part)
+__global__ __launch_bounds__(TPB) void k_finalize_beta(const double *__restrict__ part, int n, double *beta) {
+    __shared__ double sh[4];
+    const double t = sum_partials(part, n, sh);
+    if (threadIdx.x == 0) *beta = 1.0 / t;
+}
 enum { SOP_ALPHA = 0, SOP_W = 1, SOP_BETA = 2 };
 // scalar algebra of the two-loop recursion
 __global__ void k_scalar_op(int op, const double *dot, double *alpha, double *beta, double *coef) {
@@ -609,6 +762,40 @@ __global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restr
     v = block_sum(v, sh);
     d = block_sum(d, sh);
     if (live && threadIdx.x == 0) { out[0] = v; out[1] = d; if (obj_part) out[2] = o; }
+}
+// phase-1 step with the line-search result: y_head = -Grad (setAsNegGrad), R += tau D (ALMupdateVar) and
+// constrValSum += tau q1 + tau^2 q2 (lorads_alm.c:583-598,619-648,1122-1124) in one pass
+__global__ __launch_bounds__(TPB) void k_alm_update(size_t len, double tau, const double *__restrict__ G,
+                                                    const double *__restrict__ D, double *__restrict__ y, double *__restrict__ R,
+                                                    int m, const double *__restrict__ q1, const double *__restrict__ q2,
+                                                    double *__restrict__ csum) {
+    const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x, stride = (size_t)gridDim.x * TPB;
+    for (size_t i = gid; i < len; i += stride) {
+        y[i] = -1.0 * G[i];
+        R[i] += tau * D[i];
+    }
+    for (size_t i = gid; i < (size_t)m; i += stride) {
+        const double cs = csum[i] + tau * q1[i];
+        csum[i] = cs + (tau * tau) * q2[i];
+    }
+}
+// one workgroup closes the inner iteration: lagNormSq, beta of the new history pair, primal residual and b.lambda
+__global__ __launch_bounds__(TPB) void k_alm_tail(const double *__restrict__ lag_part, int nlag, double *lag_out,
+                                                  const double *__restrict__ ys_part, int nys, double *beta_out, int m,
+                                                  const double *__restrict__ b, const double *__restrict__ csum,
+                                                  const double *__restrict__ lambda, double *out) {
+    __shared__ double sh[4];
+    const double lag = sum_partials(lag_part, nlag, sh);
+    const double ys = sum_partials(ys_part, nys, sh);
+    double v = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < m; i += TPB) {
+        const double t = b[i] - csum[i];
+        v += t * t;
+        d += b[i] * lambda[i];
+    }
+    v = block_sum(v, sh);
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) { *lag_out = 1.0 * lag; *beta_out = 1.0 / ys; out[0] = v; out[1] = d; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -1479,6 +1666,38 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     const size_t n = c->all_elem;
     const int gv = grid1d(n);
     double *D = c->U;
+    if (!c->ar) { // single rank: one kernel per stage of the recursion (5 + 1 launches for history 2)
+        double *pp[2] = {part_slot(c, 3), part_slot(c, 5)};
+        int cur = 0;
+        if (inner == 0) {
+            LAUNCH(k_lbfgs_stage, gv, n, (int)ST_FIRST, (const double *)nullptr, 0, (double *)nullptr, (const double *)nullptr,
+                   (double *)nullptr, c->G, c->G, pp[cur], D);
+        } else {
+            double *q = c->Dtmp;
+            const int nn = inner <= c->L - 1 ? inner : c->L;
+            int node = (c->head - 1 + c->L) % c->L;
+            LAUNCH(k_lbfgs_stage, gv, n, (int)ST_FIRST, (const double *)nullptr, 0, (double *)nullptr, (const double *)nullptr, q,
+                   c->G, c->ring[node].s, pp[cur], (double *)nullptr);
+            for (int t = 0; t < nn; ++t) { // first loop, newest -> oldest: alpha_i = beta_i s_i.q, q -= alpha_i y_i
+                const int nxt = (node - 1 + c->L) % c->L;
+                const double *dv = t + 1 < nn ? c->ring[nxt].s : c->ring[node].y; // next dot: s of the older node, or y of the oldest
+                LAUNCH(k_lbfgs_stage, gv, n, (int)ST_ALPHA, pp[cur], gv, c->ring_ab + 2 * node, c->ring[node].y, q,
+                       (const double *)nullptr, dv, pp[cur ^ 1], (double *)nullptr);
+                cur ^= 1;
+                if (t + 1 < nn) node = nxt;
+            }
+            for (int t = 0; t < nn; ++t) { // second loop, oldest -> newest: q += (alpha_i - beta_i y_i.q) s_i
+                const int nxt = (node + 1) % c->L;
+                const bool last = t + 1 == nn;
+                LAUNCH(k_lbfgs_stage, gv, n, (int)ST_W, pp[cur], gv, c->ring_ab + 2 * node, c->ring[node].s, q,
+                       (const double *)nullptr, last ? c->G : c->ring[nxt].y, pp[cur ^ 1], last ? D : (double *)nullptr);
+                cur ^= 1;
+                node = nxt;
+            }
+        }
+        LAUNCH(k_use_grad_p, gv, n, pp[cur], gv, c->G, D);
+        return 0;
+    }
     if (inner == 0) {
         LAUNCH(k_scale_copy, gv, n, -1.0, c->G, D);
     } else {
@@ -1511,6 +1730,22 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
 
 static int enqueue_q12p12(lorads_hip_ctx *c) {
     const int m = c->m;
+    if (c->nb == 1 && !c->ar && c->blk[0].nrow == m && m > 0 && !c->blk[0].dense_c && c->blk[0].nc > 0) {
+        // one cone that sees every constraint: (R,D) and (D,D) share each row visit -- 4 launches
+        Block &B = c->blk[0];
+        const Shape sh = shape_for(B.r);
+        const double *R = c->R + B.off, *D = c->U + B.off;
+        SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rd<LG_, V2_, NS_>), nblocks_for((size_t)B.pa.ne, TPB / sh.lg), B.pa.ne, B.pa.erow,
+                                  B.pa.ecol, R, D, B.r, B.T2, B.T));
+        B.t_uv_valid = false;
+        LAUNCH(k_cv_rd, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.T, B.cv, B.row_idx, c->q12,
+               c->q12 + m);
+        const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
+        SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4),
+                                  part_slot(c, 6)));
+        LAUNCH(k_finalize2, 2, part_slot(c, 4), part_slot(c, 6), go, 2.0, 1.0, c->q12 + 2 * m);
+        return 0;
+    }
     LAUNCH(k_zero, grid1d((size_t)2 * m + 2), (size_t)2 * m + 2, c->q12, NOGUARD);
     for (int pass = 0; pass < 2; ++pass) {
         const double *X = pass == 0 ? c->R : c->U; // D lives in U
@@ -1556,6 +1791,13 @@ int lorads_hip_alm_update_var(lorads_hip_ctx *c, double tau) {
 
 int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
     Ring &h = c->ring[c->head];
+    if (!c->ar) {
+        const int g = grid1d(c->all_elem);
+        LAUNCH(k_his_two_dot, g, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
+        LAUNCH(k_finalize_beta, 1, part_slot(c, 3), g, c->ring_ab + 2 * c->head + 1);
+        c->head = (c->head + 1) % c->L;
+        return 0;
+    }
     LAUNCH(k_his_two, grid1d(c->all_elem), c->all_elem, tau, c->U, c->G, h.s, h.y);
     if (dot_to_slot(c, h.y, h.s, 9)) return 1;
     hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 9, c->ring_ab + 2 * c->head,
@@ -1585,9 +1827,25 @@ int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double ou
     return 0;
 }
 int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
-    if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
-        lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false))
+    if (c->nb == 1 && !c->ar && c->blk[0].nrow == c->m && c->m > 0 && !c->blk[0].dense_c) {
+        // one cone that sees every constraint: 7 launches for the whole second half
+        Block &B = c->blk[0];
+        Ring &h = c->ring[c->head];
+        const int gv = grid1d(c->all_elem);
+        LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum);
+        WArgs wa{};
+        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
+        sval(c, B.pu, true, W_ALM, wa, NOGUARD);
+        const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
+        LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
+        constr_val(c, B, c->R, c->R, 1.0, B.cv, CV_SET, c->csum, NOGUARD);
+        LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), gv, c->ring_ab + 2 * c->head + 1, c->m, c->b,
+               c->csum, c->lambda, c->scal);
+        c->head = (c->head + 1) % c->L;
+    } else if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
+               lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) {
         return 1;
+    }
     if (next_inner >= 0 && enqueue_alm_front(c, rho, next_inner)) return 1;
     double s[23];
     if (read_scalars(c, 0, 23, s)) return 1;
