@@ -92,6 +92,20 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     __syncthreads();
     return t;
 }
+// N sums over the workgroup with one barrier pair; sh = 4*N doubles of LDS, results in every thread.  Each value is
+// reduced exactly as block_sum reduces it.
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *sh) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        v[k] = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) sh[k * 4 + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = (sh[k * 4] + sh[k * 4 + 1]) + (sh[k * 4 + 2] + sh[k * 4 + 3]);
+    __syncthreads();
+}
 __device__ __forceinline__ double sum_partials(const double *part, int n, double *sh) {
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += TPB) v += part[i];
@@ -784,18 +798,17 @@ __global__ __launch_bounds__(TPB) void k_alm_tail(const double *__restrict__ lag
                                                   const double *__restrict__ ys_part, int nys, double *beta_out, int m,
                                                   const double *__restrict__ b, const double *__restrict__ csum,
                                                   const double *__restrict__ lambda, double *out) {
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     const double lag = sum_partials(lag_part, nlag, sh);
     const double ys = sum_partials(ys_part, nys, sh);
-    double v = 0.0, d = 0.0;
+    double vd[2] = {0.0, 0.0};
     for (int i = threadIdx.x; i < m; i += TPB) {
         const double t = b[i] - csum[i];
-        v += t * t;
-        d += b[i] * lambda[i];
+        vd[0] += t * t;
+        vd[1] += b[i] * lambda[i];
     }
-    v = block_sum(v, sh);
-    d = block_sum(d, sh);
-    if (threadIdx.x == 0) { *lag_out = 1.0 * lag; *beta_out = 1.0 / ys; out[0] = v; out[1] = d; }
+    block_sum_n<2>(vd, sh);
+    if (threadIdx.x == 0) { *lag_out = 1.0 * lag; *beta_out = 1.0 / ys; out[0] = vd[0]; out[1] = vd[1]; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -809,23 +822,33 @@ __global__ void k_csum_step(int m, double tau, const double *__restrict__ q1, co
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) { double c = csum[i] + tau * q1[i]; csum[i] = c + (tau * tau) * q2[i]; }
 }
-// five dots of the line search in one workgroup -> out[0..4]
+// five dots of the line search in one workgroup -> out[0..4]; out[5], out[6] = p1, p2, taken from the q12 tail or,
+// when the objective partials are handed over (fused step), summed here and stored in both places
 __global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const double *__restrict__ b,
                                                     const double *__restrict__ csum, const double *__restrict__ lambda,
-                                                    const double *__restrict__ q1, const double *__restrict__ q2,
-                                                    double *__restrict__ out) {
-    __shared__ double sh[4];
-    if (threadIdx.x == 0) { out[5] = q1[2 * (size_t)m]; out[6] = q1[2 * (size_t)m + 1]; } // p1, p2 ride along (q12 layout)
+                                                    double *q1, const double *__restrict__ q2, double *__restrict__ out,
+                                                    const double *__restrict__ part1, const double *__restrict__ part2,
+                                                    int npart) {
+    __shared__ double sh[20];
+    if (part1) {
+        const double t1 = sum_partials(part1, npart, sh), t2 = sum_partials(part2, npart, sh);
+        if (threadIdx.x == 0) {
+            out[5] = q1[2 * (size_t)m] = 2.0 * t1;
+            out[6] = q1[2 * (size_t)m + 1] = 1.0 * t2;
+        }
+    } else if (threadIdx.x == 0) {
+        out[5] = q1[2 * (size_t)m];
+        out[6] = q1[2 * (size_t)m + 1];
+    }
     double s[5] = {0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < m; i += TPB) {
         const double q0 = (b[i] - csum[i]) + rinv * lambda[i];
         const double a1 = q1[i], a2 = q2[i];
         s[0] += a2 * a2; s[1] += a1 * a2; s[2] += a1 * a1; s[3] += q0 * a2; s[4] += q0 * a1;
     }
-    for (int k = 0; k < 5; ++k) {
-        const double t = block_sum(s[k], sh);
-        if (threadIdx.x == 0) out[k] = t;
-    }
+    block_sum_n<5>(s, sh);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 5; ++k) out[k] = s[k];
 }
 
 // ------------------------------------------------------------------ host side
@@ -1728,7 +1751,7 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     return 0;
 }
 
-static int enqueue_q12p12(lorads_hip_ctx *c) {
+static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
     const int m = c->m;
     if (c->nb == 1 && !c->ar && c->blk[0].nrow == m && m > 0 && !c->blk[0].dense_c && c->blk[0].nc > 0) {
         // one cone that sees every constraint: (R,D) and (D,D) share each row visit -- 4 launches
@@ -1743,7 +1766,8 @@ static int enqueue_q12p12(lorads_hip_ctx *c) {
         const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
         SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4),
                                   part_slot(c, 6)));
-        LAUNCH(k_finalize2, 2, part_slot(c, 4), part_slot(c, 6), go, 2.0, 1.0, c->q12 + 2 * m);
+        if (defer_p12) *defer_p12 = go; // the caller's line-search kernel sums the partials (same order, same values)
+        else LAUNCH(k_finalize2, 2, part_slot(c, 4), part_slot(c, 6), go, 2.0, 1.0, c->q12 + 2 * m);
         return 0;
     }
     LAUNCH(k_zero, grid1d((size_t)2 * m + 2), (size_t)2 * m + 2, c->q12, NOGUARD);
@@ -1771,7 +1795,8 @@ static void quartic_coeffs(double rho, double p1, double p2, const double s[5], 
     k[3] = p1 - rho * s[4];
 }
 int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
-    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16, (const double *)nullptr,
+           (const double *)nullptr, 0);
     double s[5];
     if (read_scalars(c, 16, 5, s)) return 1;
     quartic_coeffs(rho, p1, p2, s, k);
@@ -1814,8 +1839,10 @@ int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
 // Same kernels in the same order as the slot-by-slot calls, so the results are identical; if the host leaves the
 // loop, the speculated direction is simply never used (it only touched D, q1/q2 and scratch).
 static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner) {
-    if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c)) return 1;
-    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16);
+    int np = 0;
+    if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c, &np)) return 1;
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16,
+           np ? part_slot(c, 4) : (const double *)nullptr, np ? part_slot(c, 6) : (const double *)nullptr, np);
     return 0;
 }
 int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double out[6]) {
