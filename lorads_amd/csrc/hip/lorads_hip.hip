@@ -54,7 +54,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int MAXPART = 4096; // capacity of one partial-sum slot
-constexpr int NSLOT = 10;
+constexpr int NSLOT = 18;
 
 thread_local std::string g_err;
 int fail(const char *what, hipError_t e) {
@@ -250,31 +250,15 @@ __global__ __launch_bounds__(TPB) void k_obj_rd(int ne, const int *__restrict__ 
     if (threadIdx.x == 0) { part1[blockIdx.x] = u1; part2[blockIdx.x] = u2; }
 }
 // q1 = 2 A(T1), q2 = A(T2) for a cone that sees every constraint (vec1/vec2 are SET); cv keeps the second one,
-// as the two successive k_cv passes leave it
+// as the two successive k_cv passes leave it.  The rows a workgroup owns also give its share of the seven
+// line-search sums (see k_linesearch), so no kernel has to stream the m-vectors again.
 __global__ __launch_bounds__(TPB) void k_cv_rd(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
                                                const double *__restrict__ a_val, const double *__restrict__ T1,
                                                const double *__restrict__ T2, double *__restrict__ cv,
                                                const int *__restrict__ row_idx, double *__restrict__ vec1,
-                                               double *__restrict__ vec2) {
-    const int i = (blockIdx.x * TPB + threadIdx.x) / 8, lane = threadIdx.x & 7;
-    const bool act = i < nrow;
-    double s1 = 0.0, s2 = 0.0;
-    if (act)
-        for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) {
-            const int e = a_e[t];
-            const double a = a_val[t];
-            s1 += a * T1[e];
-            s2 += a * T2[e];
-        }
-    s1 = group_sum<8>(s1);
-    s2 = group_sum<8>(s2);
-    if (act && lane == 0) {
-        const int gi = row_idx[i];
-        vec1[gi] = s1 * 2.0;
-        vec2[gi] = s2 * 1.0;
-        cv[i] = s2;
-    }
-}
+                                               double *__restrict__ vec2, const double *__restrict__ b,
+                                               const double *__restrict__ csum, const double *__restrict__ lambda,
+                                               double *__restrict__ part);
 // out[b] = scale_b * sum(part_b), b = blockIdx.x in {0, 1}
 __global__ __launch_bounds__(TPB) void k_finalize2(const double *__restrict__ part0, const double *__restrict__ part1, int n,
                                                    double scale0, double scale1, double *out) {
@@ -710,16 +694,28 @@ __global__ __launch_bounds__(TPB) void k_lbfgs_stage(size_t len, int op, const d
         }
     }
     double local = 0.0;
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
-        const double v = op == ST_FIRST ? qsrc[i] : q[i] + coef * ax[i];
-        if (dout) {
-            const double d = -1.0 * v;
-            dout[i] = d;
-            local += d * dv[i];
-        } else {
-            q[i] = v;
-            local += dv[i] * v;
-        }
+    auto one = [&](double qi, double axi, double dvi, double &store) { // one element of the stage
+        const double v = op == ST_FIRST ? qi : qi + coef * axi;
+        if (dout) { store = -1.0 * v; local += store * dvi; }
+        else { store = v; local += dvi * v; }
+    };
+    // 16-byte accesses: these stages only stream (3 vectors in, 1 out)
+    const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x, stride = (size_t)gridDim.x * TPB, n2 = len / 2;
+    const double2 *q2 = (const double2 *)(op == ST_FIRST ? qsrc : q), *ax2 = (const double2 *)ax, *dv2 = (const double2 *)dv;
+    double2 *o2 = (double2 *)(dout ? dout : q);
+    for (size_t i = gid; i < n2; i += stride) {
+        const double2 qv = q2[i], dvv = dv2[i];
+        const double2 axv = op == ST_FIRST ? qv : ax2[i];
+        double2 st;
+        one(qv.x, axv.x, dvv.x, st.x);
+        one(qv.y, axv.y, dvv.y, st.y);
+        o2[i] = st;
+    }
+    if ((len & 1) && gid == 0) {
+        const size_t i = len - 1;
+        double st;
+        one(op == ST_FIRST ? qsrc[i] : q[i], op == ST_FIRST ? 0.0 : ax[i], dv[i], st);
+        (dout ? dout : q)[i] = st;
     }
     const double t = block_sum(local, sh);
     if (threadIdx.x == 0) part_out[blockIdx.x] = t;
@@ -738,7 +734,19 @@ __global__ __launch_bounds__(TPB) void k_his_two_dot(size_t len, double tau, con
                                                      double *__restrict__ y, double *__restrict__ part) {
     __shared__ double sh[4];
     double local = 0.0;
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += (size_t)gridDim.x * TPB) {
+    const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x, stride = (size_t)gridDim.x * TPB, n2 = len / 2;
+    for (size_t i = gid; i < n2; i += stride) {
+        const double2 d = ((const double2 *)D)[i], gg = ((const double2 *)G)[i], yo = ((const double2 *)y)[i];
+        double2 si, yi;
+        si.x = tau * d.x; yi.x = yo.x + gg.x;
+        si.y = tau * d.y; yi.y = yo.y + gg.y;
+        ((double2 *)s)[i] = si;
+        ((double2 *)y)[i] = yi;
+        local += yi.x * si.x;
+        local += yi.y * si.y;
+    }
+    if ((len & 1) && gid == 0) {
+        const size_t i = len - 1;
         const double si = tau * D[i], yi = y[i] + G[i];
         s[i] = si;
         y[i] = yi;
@@ -760,21 +768,58 @@ __global__ void k_scalar_op(int op, const double *dot, double *alpha, double *be
     else if (op == SOP_W) { *coef = *alpha - *beta * *dot; }
     else { *beta = 1.0 / *dot; }
 }
-// one workgroup: out[0] = sum (b-csum)^2, out[1] = b.lambda   (primalInfeasibility, LORADSCalDualObj)
-__global__ __launch_bounds__(TPB) void k_eval_final(int m, const double *__restrict__ b, const double *__restrict__ csum,
-                                                    const double *__restrict__ lambda, double *out, Guard g,
-                                                    const double *__restrict__ obj_part, int nobj) {
+// partials of sum (b-csum)^2 and b.lambda over the m constraints (primalInfeasibility, LORADSCalDualObj) when no
+// constraint-value kernel could produce them on the way (cones that share constraints)
+__global__ __launch_bounds__(TPB) void k_eval_part(int m, const double *__restrict__ b, const double *__restrict__ csum,
+                                                   const double *__restrict__ lambda, double *__restrict__ part_v,
+                                                   double *__restrict__ part_d, Guard g) {
+    __shared__ double sh[8];
+    const bool live = !blocked(g);
+    double vd[2] = {0.0, 0.0};
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+        const double t = b[i] - csum[i];
+        vd[0] += t * t;
+        vd[1] += b[i] * lambda[i];
+    }
+    block_sum_n<2>(vd, sh);
+    if (live && threadIdx.x == 0) { part_v[blockIdx.x] = vd[0]; part_d[blockIdx.x] = vd[1]; }
+}
+// cv_i = w_i = sum_k a_k T[e_k] and vec[g_i] = w_i for a cone that sees every constraint (k_cv with CV_SET, scale 1),
+// plus the partials of sum (b - w)^2 and b.lambda over the rows this workgroup owns
+__global__ __launch_bounds__(TPB) void k_cv_res(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
+                                                const double *__restrict__ a_val, const double *__restrict__ T,
+                                                double *__restrict__ cv, const int *__restrict__ row_idx, double *__restrict__ vec,
+                                                const double *__restrict__ b, const double *__restrict__ lambda,
+                                                double *__restrict__ part_v, double *__restrict__ part_d, Guard g) {
+    __shared__ double sh[8];
+    const bool live = !blocked(g);
+    const int lane = threadIdx.x & 7, per = TPB / 8;
+    double vd[2] = {0.0, 0.0};
+    for (int i0 = blockIdx.x * per; i0 < nrow; i0 += gridDim.x * per) {
+        const int i = i0 + threadIdx.x / 8;
+        const bool act = i < nrow;
+        double s = 0.0;
+        if (act)
+            for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) s += a_val[t] * T[a_e[t]];
+        s = group_sum<8>(s);
+        if (act && lane == 0) {
+            const int gi = row_idx[i];
+            const double w = s * 1.0, bi = b[gi], t = bi - w;
+            if (live) { vec[gi] = w; cv[i] = s; }
+            vd[0] += t * t;
+            vd[1] += bi * lambda[gi];
+        }
+    }
+    block_sum_n<2>(vd, sh);
+    if (live && threadIdx.x == 0) { part_v[blockIdx.x] = vd[0]; part_d[blockIdx.x] = vd[1]; }
+}
+// one workgroup: out[0] = sum (b-csum)^2, out[1] = b.lambda from their partials, out[2] = <C, R R^T> (one cone, one rank)
+__global__ __launch_bounds__(TPB) void k_eval_final(const double *__restrict__ part_v, const double *__restrict__ part_d, int np,
+                                                    double *out, Guard g, const double *__restrict__ obj_part, int nobj) {
     __shared__ double sh[4];
     const bool live = !blocked(g);
-    const double o = obj_part ? sum_partials(obj_part, nobj, sh) : 0.0; // out[2] = <C, R R^T> (one cone, one rank)
-    double v = 0.0, d = 0.0;
-    for (int i = threadIdx.x; i < m; i += TPB) {
-        const double t = b[i] - csum[i];
-        v += t * t;
-        d += b[i] * lambda[i];
-    }
-    v = block_sum(v, sh);
-    d = block_sum(d, sh);
+    const double o = obj_part ? sum_partials(obj_part, nobj, sh) : 0.0;
+    const double v = sum_partials(part_v, np, sh), d = sum_partials(part_d, np, sh);
     if (live && threadIdx.x == 0) { out[0] = v; out[1] = d; if (obj_part) out[2] = o; }
 }
 // phase-1 step with the line-search result: y_head = -Grad (setAsNegGrad), R += tau D (ALMupdateVar) and
@@ -784,31 +829,35 @@ __global__ __launch_bounds__(TPB) void k_alm_update(size_t len, double tau, cons
                                                     int m, const double *__restrict__ q1, const double *__restrict__ q2,
                                                     double *__restrict__ csum) {
     const size_t gid = (size_t)blockIdx.x * TPB + threadIdx.x, stride = (size_t)gridDim.x * TPB;
-    for (size_t i = gid; i < len; i += stride) {
-        y[i] = -1.0 * G[i];
-        R[i] += tau * D[i];
+    const size_t n2 = len / 2;
+    for (size_t i = gid; i < n2; i += stride) {
+        const double2 gg = ((const double2 *)G)[i], d = ((const double2 *)D)[i];
+        double2 rr = ((double2 *)R)[i], yy;
+        yy.x = -1.0 * gg.x; yy.y = -1.0 * gg.y;
+        rr.x += tau * d.x; rr.y += tau * d.y;
+        ((double2 *)y)[i] = yy;
+        ((double2 *)R)[i] = rr;
+    }
+    if ((len & 1) && gid == 0) {
+        y[len - 1] = -1.0 * G[len - 1];
+        R[len - 1] += tau * D[len - 1];
     }
     for (size_t i = gid; i < (size_t)m; i += stride) {
         const double cs = csum[i] + tau * q1[i];
         csum[i] = cs + (tau * tau) * q2[i];
     }
 }
-// one workgroup closes the inner iteration: lagNormSq, beta of the new history pair, primal residual and b.lambda
+// one workgroup closes the inner iteration: lagNormSq, beta of the new history pair, primal residual and b.lambda,
+// all from partials
 __global__ __launch_bounds__(TPB) void k_alm_tail(const double *__restrict__ lag_part, int nlag, double *lag_out,
-                                                  const double *__restrict__ ys_part, int nys, double *beta_out, int m,
-                                                  const double *__restrict__ b, const double *__restrict__ csum,
-                                                  const double *__restrict__ lambda, double *out) {
-    __shared__ double sh[8];
+                                                  const double *__restrict__ ys_part, int nys, double *beta_out,
+                                                  const double *__restrict__ part_v, const double *__restrict__ part_d, int np,
+                                                  double *out) {
+    __shared__ double sh[4];
     const double lag = sum_partials(lag_part, nlag, sh);
     const double ys = sum_partials(ys_part, nys, sh);
-    double vd[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < m; i += TPB) {
-        const double t = b[i] - csum[i];
-        vd[0] += t * t;
-        vd[1] += b[i] * lambda[i];
-    }
-    block_sum_n<2>(vd, sh);
-    if (threadIdx.x == 0) { *lag_out = 1.0 * lag; *beta_out = 1.0 / ys; out[0] = vd[0]; out[1] = vd[1]; }
+    const double v = sum_partials(part_v, np, sh), d = sum_partials(part_d, np, sh);
+    if (threadIdx.x == 0) { *lag_out = 1.0 * lag; *beta_out = 1.0 / ys; out[0] = v; out[1] = d; }
 }
 // lambda += rho b - rho csum
 __global__ void k_dual_update(int m, double rho, const double *__restrict__ b, const double *__restrict__ csum,
@@ -822,33 +871,83 @@ __global__ void k_csum_step(int m, double tau, const double *__restrict__ q1, co
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) { double c = csum[i] + tau * q1[i]; csum[i] = c + (tau * tau) * q2[i]; }
 }
-// five dots of the line search in one workgroup -> out[0..4]; out[5], out[6] = p1, p2, taken from the q12 tail or,
-// when the objective partials are handed over (fused step), summed here and stored in both places
-__global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const double *__restrict__ b,
-                                                    const double *__restrict__ csum, const double *__restrict__ lambda,
-                                                    double *q1, const double *__restrict__ q2, double *__restrict__ out,
-                                                    const double *__restrict__ part1, const double *__restrict__ part2,
-                                                    int npart) {
-    __shared__ double sh[20];
+// Line search sums (lorads_alm.c:164-172).  With q0 = (b - csum) + lambda / rho the five dots are
+//   ||q2||^2, q1.q2, ||q1||^2, q0.q2, q0.q1;  the rho-free pieces are accumulated as SEVEN partial sums per workgroup
+//   {q2.q2, q1.q2, q1.q1, (b-csum).q2, lambda.q2, (b-csum).q1, lambda.q1}  (slot k at part + k * MAXPART)
+// either by the kernel that produces q1, q2 (k_cv_rd) or by k_linesearch_part; k_linesearch adds them up.
+constexpr int LS_NSUM = 7;
+__device__ __forceinline__ void ls_accumulate(double (&s)[LS_NSUM], double a1, double a2, double bc, double lam) {
+    s[0] += a2 * a2; s[1] += a1 * a2; s[2] += a1 * a1; s[3] += bc * a2; s[4] += lam * a2; s[5] += bc * a1; s[6] += lam * a1;
+}
+__global__ __launch_bounds__(TPB) void k_cv_rd(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_e,
+                                               const double *__restrict__ a_val, const double *__restrict__ T1,
+                                               const double *__restrict__ T2, double *__restrict__ cv,
+                                               const int *__restrict__ row_idx, double *__restrict__ vec1,
+                                               double *__restrict__ vec2, const double *__restrict__ b,
+                                               const double *__restrict__ csum, const double *__restrict__ lambda,
+                                               double *__restrict__ part) {
+    __shared__ double sh[4 * LS_NSUM];
+    const int lane = threadIdx.x & 7, per = TPB / 8;
+    double acc[LS_NSUM] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i0 = blockIdx.x * per; i0 < nrow; i0 += gridDim.x * per) {
+        const int i = i0 + threadIdx.x / 8;
+        const bool act = i < nrow;
+        double s1 = 0.0, s2 = 0.0;
+        if (act)
+            for (int t = a_ptr[i] + lane; t < a_ptr[i + 1]; t += 8) {
+                const int e = a_e[t];
+                const double a = a_val[t];
+                s1 += a * T1[e];
+                s2 += a * T2[e];
+            }
+        s1 = group_sum<8>(s1);
+        s2 = group_sum<8>(s2);
+        if (act && lane == 0) {
+            const int gi = row_idx[i];
+            const double a1 = s1 * 2.0, a2 = s2 * 1.0;
+            vec1[gi] = a1;
+            vec2[gi] = a2;
+            cv[i] = s2;
+            ls_accumulate(acc, a1, a2, b[gi] - csum[gi], lambda[gi]);
+        }
+    }
+    block_sum_n<LS_NSUM>(acc, sh);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < LS_NSUM; ++k) part[(size_t)k * MAXPART + blockIdx.x] = acc[k];
+}
+__global__ __launch_bounds__(TPB) void k_linesearch_part(int m, const double *__restrict__ b, const double *__restrict__ csum,
+                                                         const double *__restrict__ lambda, const double *__restrict__ q1,
+                                                         const double *__restrict__ q2, double *__restrict__ part) {
+    __shared__ double sh[4 * LS_NSUM];
+    double s[LS_NSUM] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) ls_accumulate(s, q1[i], q2[i], b[i] - csum[i], lambda[i]);
+    block_sum_n<LS_NSUM>(s, sh);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < LS_NSUM; ++k) part[(size_t)k * MAXPART + blockIdx.x] = s[k];
+}
+// one workgroup: out[0..4] = the five dots, out[5], out[6] = p1, p2 -- taken from the q12 tail or, when the objective
+// partials are handed over (fused step), summed here and stored in both places
+__global__ __launch_bounds__(TPB) void k_linesearch(int m, double rinv, const double *__restrict__ part, int np, double *q12,
+                                                    double *__restrict__ out, const double *__restrict__ part1,
+                                                    const double *__restrict__ part2, int npart) {
+    __shared__ double sh[4];
     if (part1) {
         const double t1 = sum_partials(part1, npart, sh), t2 = sum_partials(part2, npart, sh);
         if (threadIdx.x == 0) {
-            out[5] = q1[2 * (size_t)m] = 2.0 * t1;
-            out[6] = q1[2 * (size_t)m + 1] = 1.0 * t2;
+            out[5] = q12[2 * (size_t)m] = 2.0 * t1;
+            out[6] = q12[2 * (size_t)m + 1] = 1.0 * t2;
         }
     } else if (threadIdx.x == 0) {
-        out[5] = q1[2 * (size_t)m];
-        out[6] = q1[2 * (size_t)m + 1];
+        out[5] = q12[2 * (size_t)m];
+        out[6] = q12[2 * (size_t)m + 1];
     }
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < m; i += TPB) {
-        const double q0 = (b[i] - csum[i]) + rinv * lambda[i];
-        const double a1 = q1[i], a2 = q2[i];
-        s[0] += a2 * a2; s[1] += a1 * a2; s[2] += a1 * a1; s[3] += q0 * a2; s[4] += q0 * a1;
+    double s[LS_NSUM];
+    for (int k = 0; k < LS_NSUM; ++k) s[k] = sum_partials(part + (size_t)k * MAXPART, np, sh);
+    if (threadIdx.x == 0) {
+        out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+        out[3] = s[3] + rinv * s[4];
+        out[4] = s[5] + rinv * s[6];
     }
-    block_sum_n<5>(s, sh);
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 5; ++k) out[k] = s[k];
 }
 
 // ------------------------------------------------------------------ host side
@@ -926,6 +1025,7 @@ struct lorads_hip_ctx {
     double *Dtmp = nullptr;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
     double *part = nullptr;   // NSLOT x MAXPART partial sums
+    int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
     char *ctrl = nullptr, *h_ctrl = nullptr; // [64 scalars | CG states] device + pinned mirror: ONE readback copy
     double *scal = nullptr;   // 64 device scalars
     CGState *st = nullptr;    // one per (cone, half)
@@ -949,9 +1049,15 @@ struct lorads_hip_ctx {
 namespace {
 
 inline int nblocks_for(size_t items, int per_block) { return (int)((items + per_block - 1) / per_block); }
+// grid of the L-BFGS stage kernels: every workgroup re-sums the previous stage's partials, so keep them few
+inline int grid_lbfgs(size_t len);
 inline int grid1d(size_t len) {
     size_t g = (len + TPB - 1) / TPB;
     return (int)std::min<size_t>(std::max<size_t>(g, 1), 2048);
+}
+inline int grid_lbfgs(size_t len) {
+    static const int cap = getenv("LORADS_LBFGS_GRID") ? atoi(getenv("LORADS_LBFGS_GRID")) : 512;
+    return std::min(grid1d(len), cap);
 }
 // lanes per row/entry: 16-byte loads (2 columns per lane) when r is even and fits 8 lanes x 8 steps x 2
 inline bool use_v2(int r) { return (r % 2) == 0 && r <= 128; }
@@ -1495,12 +1601,21 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
     const Guard g{nullptr, need};
     if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, g);
     const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
+    const bool fold_res = single && !c->ar && c->m > 0; // the constraint-value kernel also delivers the residual partials
+    c->ls_np = 0;
     if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
     bool first_obj = true;
     const bool fold_obj = c->nb == 1 && !c->ar; // the final kernel sums the objective partials itself
-    int nobj = 0;
+    int nobj = 0, nres = 0;
     for (auto &B : c->blk) {
-        constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
+        if (fold_res) {
+            pairdots(c, B.pa, c->R + B.off, c->R + B.off, B.r, B.T2, g);
+            nres = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 2048);
+            LAUNCH(k_cv_res, nres, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.cv, B.row_idx, c->csum, c->b, c->lambda, part_slot(c, 8),
+                   part_slot(c, 9), g);
+        } else {
+            constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
+        }
         if (!with_obj) continue; // DIMACS refresh alone (lorads_alg_common.c:250-290) does not touch the objective
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
         if (fold_obj) { nobj = go; continue; }
@@ -1512,8 +1627,12 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
         if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
         HC(hipMemcpyAsync(c->scal + 2, c->csum + c->m, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
-    LAUNCH(k_eval_final, 1, c->m, c->b, c->csum, c->lambda, c->scal, g, (fold_obj && nobj > 0) ? part_slot(c, 4) : (const double *)nullptr,
-           nobj);
+    if (!fold_res) {
+        nres = std::min(grid1d((size_t)c->m), 1024);
+        LAUNCH(k_eval_part, nres, c->m, c->b, c->csum, c->lambda, part_slot(c, 8), part_slot(c, 9), g);
+    }
+    LAUNCH(k_eval_final, 1, part_slot(c, 8), part_slot(c, 9), nres, c->scal, g,
+           (fold_obj && nobj > 0) ? part_slot(c, 4) : (const double *)nullptr, nobj);
     return 0;
 }
 
@@ -1660,6 +1779,7 @@ int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
+    c->ls_np = 0;
     const double *X = pair == LORADS_HIP_PAIR_RR ? c->R : c->U, *Y = pair == LORADS_HIP_PAIR_RR ? c->R : c->V;
     LAUNCH(k_zero, grid1d((size_t)c->m + 2), (size_t)c->m + 2, c->csum, NOGUARD);
     for (auto &B : c->blk) constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, CV_ADD, c->csum, NOGUARD);
@@ -1687,7 +1807,7 @@ int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
 int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     for (auto &B : c->blk) B.t_uv_valid = false; // U is overwritten by the direction D
     const size_t n = c->all_elem;
-    const int gv = grid1d(n);
+    const int gv = c->ar ? grid1d(n) : grid_lbfgs(n);
     double *D = c->U;
     if (!c->ar) { // single rank: one kernel per stage of the recursion (5 + 1 launches for history 2)
         double *pp[2] = {part_slot(c, 3), part_slot(c, 5)};
@@ -1761,8 +1881,9 @@ static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
         SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rd<LG_, V2_, NS_>), nblocks_for((size_t)B.pa.ne, TPB / sh.lg), B.pa.ne, B.pa.erow,
                                   B.pa.ecol, R, D, B.r, B.T2, B.T));
         B.t_uv_valid = false;
-        LAUNCH(k_cv_rd, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.T, B.cv, B.row_idx, c->q12,
-               c->q12 + m);
+        c->ls_np = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
+        LAUNCH(k_cv_rd, c->ls_np, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.T, B.cv, B.row_idx, c->q12, c->q12 + m, c->b, c->csum,
+               c->lambda, part_slot(c, 10));
         const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
         SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4),
                                   part_slot(c, 6)));
@@ -1770,6 +1891,7 @@ static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
         else LAUNCH(k_finalize2, 2, part_slot(c, 4), part_slot(c, 6), go, 2.0, 1.0, c->q12 + 2 * m);
         return 0;
     }
+    c->ls_np = 0;
     LAUNCH(k_zero, grid1d((size_t)2 * m + 2), (size_t)2 * m + 2, c->q12, NOGUARD);
     for (int pass = 0; pass < 2; ++pass) {
         const double *X = pass == 0 ? c->R : c->U; // D lives in U
@@ -1794,9 +1916,17 @@ static void quartic_coeffs(double rho, double p1, double p2, const double s[5], 
     k[2] = p2 - rho * s[3] + rho * s[2] / 2;
     k[3] = p1 - rho * s[4];
 }
+// the five dots (+ p1, p2) into scal[16..22]; np_obj > 0: the objective partials of q12p12 are still to be summed
+static void launch_linesearch(lorads_hip_ctx *c, double rho, int np_obj) {
+    if (c->ls_np == 0) { // q1, q2 came from the general path: stream the m-vectors once, many workgroups
+        c->ls_np = std::min(grid1d((size_t)c->m), 1024);
+        LAUNCH(k_linesearch_part, c->ls_np, c->m, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, part_slot(c, 10));
+    }
+    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, part_slot(c, 10), c->ls_np, c->q12, c->scal + 16,
+           np_obj ? part_slot(c, 4) : (const double *)nullptr, np_obj ? part_slot(c, 6) : (const double *)nullptr, np_obj);
+}
 int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
-    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16, (const double *)nullptr,
-           (const double *)nullptr, 0);
+    launch_linesearch(c, rho, 0);
     double s[5];
     if (read_scalars(c, 16, 5, s)) return 1;
     quartic_coeffs(rho, p1, p2, s, k);
@@ -1809,6 +1939,7 @@ int lorads_hip_set_y_as_neg_grad(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_alm_update_var(lorads_hip_ctx *c, double tau) {
+    c->ls_np = 0;
     LAUNCH(k_axpy, grid1d(c->all_elem), c->all_elem, tau, c->U, c->R);
     LAUNCH(k_csum_step, nblocks_for((size_t)c->m, TPB), c->m, tau, c->q12, c->q12 + c->m, c->csum);
     return 0;
@@ -1817,7 +1948,7 @@ int lorads_hip_alm_update_var(lorads_hip_ctx *c, double tau) {
 int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
     Ring &h = c->ring[c->head];
     if (!c->ar) {
-        const int g = grid1d(c->all_elem);
+        const int g = grid_lbfgs(c->all_elem);
         LAUNCH(k_his_two_dot, g, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
         LAUNCH(k_finalize_beta, 1, part_slot(c, 3), g, c->ring_ab + 2 * c->head + 1);
         c->head = (c->head + 1) % c->L;
@@ -1841,8 +1972,7 @@ int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
 static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner) {
     int np = 0;
     if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c, &np)) return 1;
-    LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, c->scal + 16,
-           np ? part_slot(c, 4) : (const double *)nullptr, np ? part_slot(c, 6) : (const double *)nullptr, np);
+    launch_linesearch(c, rho, np);
     return 0;
 }
 int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double out[6]) {
@@ -1858,16 +1988,20 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         // one cone that sees every constraint: 7 launches for the whole second half
         Block &B = c->blk[0];
         Ring &h = c->ring[c->head];
-        const int gv = grid1d(c->all_elem);
+        const int gv = grid_lbfgs(c->all_elem);
+        c->ls_np = 0;
         LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum);
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
         const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
         LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
-        constr_val(c, B, c->R, c->R, 1.0, B.cv, CV_SET, c->csum, NOGUARD);
-        LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), gv, c->ring_ab + 2 * c->head + 1, c->m, c->b,
-               c->csum, c->lambda, c->scal);
+        pairdots(c, B.pa, c->R, c->R, B.r, B.T2, NOGUARD);
+        const int nres = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 2048);
+        LAUNCH(k_cv_res, nres, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.cv, B.row_idx, c->csum, c->b, c->lambda, part_slot(c, 8),
+               part_slot(c, 9), NOGUARD);
+        LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), gv, c->ring_ab + 2 * c->head + 1, part_slot(c, 8),
+               part_slot(c, 9), nres, c->scal);
         c->head = (c->head + 1) % c->L;
     } else if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
                lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) {
@@ -1924,6 +2058,7 @@ int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxi
 }
 
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
+    c->ls_np = 0;
     LAUNCH(k_dual_update, nblocks_for((size_t)c->m, TPB), c->m, rho, c->b, c->csum, c->lambda);
     return 0;
 }
@@ -1954,6 +2089,7 @@ int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
+    c->ls_np = 0;
     for (auto &B : c->blk) {
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
@@ -1989,6 +2125,7 @@ int lorads_hip_get_mat(lorads_hip_ctx *c, int32_t which, int32_t k, double *cm) 
 }
 
 int lorads_hip_set_vec(lorads_hip_ctx *c, int32_t which, const double *v) {
+    c->ls_np = 0;
     double *d = vec_base(c, which);
     if (!d) return fail_msg("set_vec: bad argument");
     HC(hipMemcpyAsync(d, v, sizeof(double) * (size_t)c->m, hipMemcpyHostToDevice, c->stream));

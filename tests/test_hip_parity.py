@@ -191,7 +191,10 @@ def test_fused_step_equals_separate_calls(built, name):
             cb = b.be.admm_update_var(rho, tol, 800)
             pb, db, eb = b.be.cal_obj(host.PAIR_UV), b.be.cal_dual_obj(), b.be.update_dimacs(host.PAIR_UV)
             assert ca == cb, (it, ca, cb)
-            assert pa == pb and da == db and ea == eb, (it, pa, pb, da, db, ea, eb)
+            # b.lambda is summed over different workgroup partitions by the two paths (constraint-kernel partials vs
+            # the flat dot of cal_dual_obj): equal to rounding; everything that feeds the iterates is identical
+            assert pa == pb and ea == eb, (it, pa, pb, ea, eb)
+            assert da == pytest.approx(db, rel=1e-14), (it, da, db)
             for k in range(a.nblk):
                 assert np.array_equal(a.be.get_mat(host.MAT_U, k), b.be.get_mat(host.MAT_U, k))
                 assert np.array_equal(a.be.get_mat(host.MAT_V, k), b.be.get_mat(host.MAT_V, k))
