@@ -474,6 +474,84 @@ __global__ __launch_bounds__(TPB) void k_op_diag(int n, const double *__restrict
     if (live && threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// Cones whose constraints each hold ONE pattern entry (matrix completion: A_k = a (e_i e_j^T + e_j e_i^T)/2 ...):
+// w_i = a_i T_e and S_e = (sum_i a_i^2) T_e = ge_e T_e stay entry-local, so the whole operator is one row-centric pass
+//   out_p = x_p + sum_{(q,e) adjacent to p} ge_e (x_p.V_q + x_q.V_p) V_q        (q = p: ge_e (x_p.V_p) V_p)
+// -- no T, no S, no second and third kernel.  Every entry is visited from both of its rows (the pair dot is formed
+// twice); what it saves is two launches and the 4-rows-per-entry gather of the pair-dot kernel.
+template <int LG, bool V2, int NS>
+__global__ __launch_bounds__(TPB) void k_op_entry(int n, const int *__restrict__ adj_ptr, const int *__restrict__ adj_col,
+                                                  const int *__restrict__ adj_e, const double *__restrict__ ge,
+                                                  const double *__restrict__ V, int r, int mode, const double *__restrict__ xin,
+                                                  const double *__restrict__ rhs, double *__restrict__ out,
+                                                  double *__restrict__ part, Guard g) {
+    __shared__ double sh[4];
+    const bool live = !blocked(g);
+    constexpr int W = V2 ? 2 : 1;
+    const int row = (blockIdx.x * TPB + threadIdx.x) / LG, lane = threadIdx.x % LG;
+    const bool act = row < n;
+    const int rowc = act ? row : 0;
+    const size_t base = (size_t)rowc * r;
+    const int t0 = adj_ptr[rowc], t1 = act ? adj_ptr[rowc + 1] : t0;
+    double xp[NS][W], vp[NS][W], rh[NS][W], acc[NS][W];
+    Slice<LG, V2, NS>::load(xin + base, r, lane, xp);
+    Slice<LG, V2, NS>::load(V + base, r, lane, vp);
+    if (mode == OP_RES) Slice<LG, V2, NS>::load(rhs + base, r, lane, rh);
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[c][w] = 0.0;
+    for (int t = t0; t < t1; t += 2) { // two neighbours per trip: 4 row gathers in flight
+        int q[2], e[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tt = t + u < t1 ? t + u : t1 - 1;
+            q[u] = adj_col[tt];
+            e[u] = adj_e[tt];
+        }
+        double gc[2], xq[2][NS][W], vq[2][NS][W];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            gc[u] = ge[e[u]];
+            Slice<LG, V2, NS>::load(xin + (size_t)q[u] * r, r, lane, xq[u]);
+            Slice<LG, V2, NS>::load(V + (size_t)q[u] * r, r, lane, vq[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS; ++c)
+#pragma unroll
+                for (int w = 0; w < W; ++w) { s1 += xp[c][w] * vq[u][c][w]; s2 += xq[u][c][w] * vp[c][w]; }
+            double td = q[u] == rowc ? s1 : s1 + s2;
+            td = group_sum<LG>(td);
+            const double su = t + u < t1 ? gc[u] * td : 0.0;
+#pragma unroll
+            for (int c = 0; c < NS; ++c)
+#pragma unroll
+                for (int w = 0; w < W; ++w) acc[c][w] += su * vq[u][c][w];
+        }
+    }
+    double local = 0.0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        const int j0 = (lane + c * LG) * W;
+        double v[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            v[w] = xp[c][w] + acc[c][w];
+            if (mode == OP_CG) local += xp[c][w] * v[w];
+            else { v[w] = rh[c][w] - v[w]; local += v[w] * v[w]; }
+        }
+        if (live && act && j0 < r) {
+            if (V2) *(double2 *)(out + base + j0) = make_double2(v[0], v[W - 1]);
+            else out[base + j0] = v[0];
+        }
+    }
+    const double t = block_sum(act ? local : 0.0, sh);
+    if (live && threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
 // Dense objective matrix: W = C X with C dense symmetric (n_pad x n_pad row-major, zero padded) and X n x r
 // row-major -- the reference's dense branch (unpack + dsymm, lorads_sdp_data.c:646-671) -- on the FP64 matrix
 // cores: v_mfma_f64_16x16x4_f64.  Workgroup (bx, by): 64 rows of C (16 per wave) x the by-th K range
@@ -1003,6 +1081,8 @@ struct Block {
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
+    bool entry_only = false;  // every A_i is a single (off-)diagonal entry (matrix completion): k_op_entry
+    double *gentry = nullptr; // sum of a_i^2 per A-pattern entry
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
     int spec[2] = {1, 1};     // speculated CG iterations of the U- and V-solve
     double bytes_mv = 0, bytes_cg = 0;
@@ -1248,6 +1328,14 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     }
     B.diag_only = diag;
     if (diag && upload(&B.gdiag, gd)) return 1;
+    bool single_entry = !diag && B.nrow > 0 && !getenv("LORADS_NO_OP_ENTRY");
+    for (int i = 0; i < hb.nrow && single_entry; ++i) single_entry = hb.a_ptr[i + 1] - hb.a_ptr[i] == 1;
+    if (single_entry) {
+        std::vector<double> gev((size_t)B.pa.ne, 0.0);
+        for (int i = 0; i < hb.nrow; ++i) gev[a_e[hb.a_ptr[i]]] += hb.a_val[hb.a_ptr[i]] * hb.a_val[hb.a_ptr[i]];
+        if (upload(&B.gentry, gev)) return 1;
+        B.entry_only = true;
+    }
     if (!diag && build_gram(B, hb, a_e, B.pa.ne)) return 1;
     return 0;
 }
@@ -1392,6 +1480,14 @@ int op_diag(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const 
     SHAPE_DISPATCH(sh, LAUNCH((k_op_diag<LG_, V2_, NS_>), grid, B.n, B.gdiag, V, B.r, mode, xin, rhs, out, part, g));
     return grid;
 }
+int op_entry(lorads_hip_ctx *c, const Block &B, const double *V, int mode, const double *xin, const double *rhs, double *out,
+             double *part, Guard g) {
+    const Shape sh = shape_for(B.r);
+    const int grid = nblocks_for((size_t)B.n, TPB / sh.lg);
+    SHAPE_DISPATCH(sh, LAUNCH((k_op_entry<LG_, V2_, NS_>), grid, B.n, B.pa.adj_ptr, B.pa.adj_col, B.pa.adj_e, B.gentry, V, B.r, mode, xin,
+                              rhs, out, part, g));
+    return grid;
+}
 int obj_partials(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double *part, Guard g) {
     if (B.nc == 0) return 0;
     if (B.dense_c) { // <C, sym(X Y^T)> = sum_p X_p . (C Y)_p for symmetric C
@@ -1439,6 +1535,8 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
     int grid;
     if (B.diag_only) {
         grid = op_diag(c, B, V, mode, x, rhs, out, part, g);
+    } else if (B.entry_only) {
+        grid = op_entry(c, B, V, mode, x, rhs, out, part, g);
     } else {
         // x and V are this cone's (U,V) in either order and B.T already holds their pair dots
         const bool is_uv = (x == c->U + B.off && V == c->V + B.off) || (x == c->V + B.off && V == c->U + B.off);
@@ -1740,7 +1838,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     for (auto &B : c->blk) {
         B.pa.release(); B.pu.release();
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.cv); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.g_ptr); hipFree(B.g_col);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
     free_factors(c);
