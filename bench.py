@@ -285,6 +285,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
         dist.all_reduce(c)
         cg_iters = int(c.item())
     b_mv, b_cg = s.hip_algorithmic_bytes(0)
+    op_kernels = s.hip_operator_kind(0)
     out = None
     if rank == 0:
         mv_ms = prof["sampled_ms"] / prof["sampled"] if prof["sampled"] else float("nan")
@@ -305,7 +306,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
                        "parallelism": ("block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration (%s)" % ar_mode) if world > 1 else "single GPU",
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (a.times_log_rank, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
-            "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x) (k_pairdots+k_cv_from_T+k_sval+k_spmm, or k_op_diag)",
+            "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x): %s" % op_kernels,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "algorithmic_bytes_per_launch": b_mv, "avg_launch_ms": mv_ms,

@@ -2298,6 +2298,13 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
     return 0;
 }
 
+int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
+    if (k < 0 || k >= c->nb) return fail_msg("bad block");
+    const Block &B = c->blk[k];
+    *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.has_gram ? 0 : 1;
+    return 0;
+}
+
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *c, int32_t k, double *mv, double *cg) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
     *mv = c->blk[k].bytes_mv;

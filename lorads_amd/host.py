@@ -337,6 +337,7 @@ class Session:
             lib.lorads_hip_profile_read.argtypes = [C.c_void_p, _dp]
             lib.lorads_hip_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
             lib.lorads_hip_sync.argtypes = [C.c_void_p]
+            lib.lorads_hip_operator_kind.argtypes = [C.c_void_p, C.c_int, _ip]
             lib.lorads_hip_stream.restype = C.c_void_p
             lib.lorads_hip_stream.argtypes = [C.c_void_p]
             lib.lorads_hip_set_allreduce_stream_ordered.argtypes = [C.c_void_p, C.c_int]
@@ -372,6 +373,12 @@ class Session:
         v, lm, mv = C.c_double(), (C.c_double * max(nb, 1))(), C.c_int()
         _check(lib.lorads_hip_dual_infeasibility(ctx, tol, ncv, max_restarts, C.byref(v), lm, C.byref(mv)), "dual_infeasibility")
         return v.value, [lm[i] for i in range(nb)], mv.value
+
+    def hip_operator_kind(self, blk=0):
+        lib, ctx = self._hip()
+        k = C.c_int()
+        _check(lib.lorads_hip_operator_kind(ctx, blk, C.byref(k)), "operator_kind")
+        return ["k_pairdots+k_sgram+k_spmm", "k_pairdots+k_cv+k_sval+k_spmm", "k_op_diag", "k_op_entry"][k.value]
 
     def hip_stream(self):
         """hipStream_t of the library as an integer (torch.cuda.ExternalStream takes it)"""
