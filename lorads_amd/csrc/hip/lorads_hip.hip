@@ -1067,6 +1067,7 @@ struct Block {
     int *g_ptr = nullptr, *g_col = nullptr;
     double *g_val = nullptr;
     double *T = nullptr;      // pair dots on the A-pattern
+    bool cv_borrowed = false; // cv points into the merged cone's array
     double *cv = nullptr;     // constrVal[k], compact
     double *wtmp = nullptr;   // compact weights inside the CG operator
     int *c_row = nullptr, *c_col = nullptr;
@@ -1099,6 +1100,9 @@ struct lorads_hip_ctx {
     double b_nrm1 = 0;
     hipStream_t stream = nullptr;
     std::vector<Block> blk;
+    Block merged;             // all cones as ONE block-diagonal cone (see build_merged); valid when has_merged
+    bool has_merged = false;
+    bool merged_ok = false;   // structure allows it (separable constraints, no dense C); ranks decide has_merged
     size_t all_elem = 0;
     double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
     double *cr = nullptr, *cp = nullptr, *cQ = nullptr, *rhs = nullptr; // flat CG vectors
@@ -1365,6 +1369,82 @@ int alloc_factors(lorads_hip_ctx *c) {
     }
     HC(hipDeviceSynchronize());
     return 0;
+}
+// The cone the single-cone fast paths may run on: the only cone, or the block-diagonal union of all cones.
+Block *solo(lorads_hip_ctx *c) {
+    if (c->ar) return nullptr;
+    if (c->nb == 1) return &c->blk[0];
+    return c->has_merged ? &c->merged : nullptr;
+}
+
+// Several cones with block-separable constraints (every constraint lives in exactly one cone) and equal rank are,
+// for every kernel that has no per-cone scalar, ONE cone with a block-diagonal pattern: the flat factor arrays are
+// already the concatenation of the cones' n_k x r row-major factors.  Phase 1 (no per-cone scalars at all: the
+// L-BFGS runs over the concatenation, lorads_alm.c:230-391) and the evaluation part of phase 2 then cost the
+// launches of one cone instead of nb.  The CG solves keep their per-cone launches (per-cone alpha, beta, stopping).
+int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
+    c->merged_ok = c->has_merged = false;
+    if (c->nb < 2 || getenv("LORADS_NO_MERGE")) return 0;
+    std::vector<char> seen((size_t)std::max(c->m, 1), 0);
+    size_t ntot = 0, nrow = 0, na = 0, nc = 0;
+    for (int k = 0; k < c->nb; ++k) {
+        const lorads_hip_block &hb = prob->blocks[k];
+        if (c->blk[k].dense_c) return 0;
+        for (int i = 0; i < hb.nrow; ++i) {
+            if (seen[hb.row_idx[i]]) return 0; // a constraint couples two cones: the sweep order matters
+            seen[hb.row_idx[i]] = 1;
+        }
+        ntot += hb.n; nrow += hb.nrow; na += hb.a_ptr[hb.nrow]; nc += hb.c_nnz;
+    }
+    if ((int)nrow != c->m || nblocks_for(ntot, TPB / 8) > MAXPART) return 0; // partial-sum slots (refresh_merged re-checks per rank)
+    std::vector<int> row_idx, a_ptr(1, 0), a_row, a_col, c_row, c_col;
+    std::vector<double> a_val, c_val;
+    row_idx.reserve(nrow); a_row.reserve(na); a_col.reserve(na); a_val.reserve(na);
+    c_row.reserve(nc); c_col.reserve(nc); c_val.reserve(nc);
+    int roff = 0;
+    for (int k = 0; k < c->nb; ++k) {
+        const lorads_hip_block &hb = prob->blocks[k];
+        for (int i = 0; i < hb.nrow; ++i) {
+            row_idx.push_back(hb.row_idx[i]);
+            for (int t = hb.a_ptr[i]; t < hb.a_ptr[i + 1]; ++t) {
+                a_row.push_back(hb.a_row[t] + roff); a_col.push_back(hb.a_col[t] + roff); a_val.push_back(hb.a_val[t]);
+            }
+            a_ptr.push_back((int)a_row.size());
+        }
+        for (int t = 0; t < hb.c_nnz; ++t) {
+            c_row.push_back(hb.c_row[t] + roff); c_col.push_back(hb.c_col[t] + roff); c_val.push_back(hb.c_val[t]);
+        }
+        roff += hb.n;
+    }
+    lorads_hip_block mb;
+    mb.n = (int)ntot; mb.rank = prob->blocks[0].rank; mb.nrow = (int)nrow; mb.row_idx = row_idx.data(); mb.a_ptr = a_ptr.data();
+    mb.a_row = a_row.data(); mb.a_col = a_col.data(); mb.a_val = a_val.data(); mb.c_nnz = (int)nc; mb.c_row = c_row.data();
+    mb.c_col = c_col.data(); mb.c_val = c_val.data();
+    if (build_block(c, c->merged, mb)) return 1;
+    if (c->merged.dense_c) return fail_msg("internal: merged cone classified dense");
+    c->merged.off = 0;
+    // one constrVal array: the cones' compact vectors are consecutive pieces of the merged one
+    size_t o = 0;
+    for (auto &B : c->blk) {
+        hipFree(B.cv);
+        B.cv = c->merged.cv + o;
+        B.cv_borrowed = true;
+        o += (size_t)B.nrow;
+    }
+    c->merged_ok = true;
+    return 0;
+}
+// equal ranks -> the merged view is usable
+void refresh_merged(lorads_hip_ctx *c) {
+    c->has_merged = false;
+    if (!c->merged_ok) return;
+    for (auto &B : c->blk)
+        if (B.r != c->blk[0].r) return;
+    if (nblocks_for((size_t)c->merged.n, TPB / lg_for(c->blk[0].r)) > MAXPART) return;
+    c->merged.r = c->blk[0].r;
+    c->merged.t_uv_valid = false;
+    block_bytes(c->merged);
+    c->has_merged = true;
 }
 void free_factors(lorads_hip_ctx *c) {
     double *arrs[] = {c->R, c->U, c->V, c->G, c->cr, c->cp, c->cQ, c->rhs, c->Dtmp};
@@ -1698,14 +1778,20 @@ int first_unfinished(lorads_hip_ctx *c, int first) {
 int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = true) {
     const Guard g{nullptr, need};
     if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, g);
-    const bool single = c->nb == 1 && c->blk[0].nrow == c->m;
+    Block *S1 = solo(c);
+    if (S1 && (S1->nrow != c->m || S1->dense_c)) S1 = c->nb == 1 ? S1 : nullptr;
+    const bool single = (S1 && S1->nrow == c->m) || (c->nb == 1 && c->blk[0].nrow == c->m);
     const bool fold_res = single && !c->ar && c->m > 0; // the constraint-value kernel also delivers the residual partials
     c->ls_np = 0;
     if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
     bool first_obj = true;
-    const bool fold_obj = c->nb == 1 && !c->ar; // the final kernel sums the objective partials itself
+    const bool fold_obj = (c->nb == 1 || S1) && !c->ar; // the final kernel sums the objective partials itself
     int nobj = 0, nres = 0;
-    for (auto &B : c->blk) {
+    std::vector<Block *> cones;
+    if (S1) cones.push_back(S1);
+    else for (auto &B0 : c->blk) cones.push_back(&B0);
+    for (Block *bp : cones) {
+        Block &B = *bp;
         if (fold_res) {
             pairdots(c, B.pa, c->R + B.off, c->R + B.off, B.r, B.T2, g);
             nres = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 2048);
@@ -1805,6 +1891,10 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->blk.resize(c->nb);
     for (int k = 0; k < c->nb; ++k)
         if (build_block(c, c->blk[k], prob->blocks[k])) { lorads_hip_destroy(c); return 1; }
+    if (build_merged(c, prob)) { lorads_hip_destroy(c); return 1; }
+    refresh_merged(c);
+    if (getenv("LORADS_HIP_VERBOSE"))
+        fprintf(stderr, "lorads_hip: %d cone(s), merged view %s\n", c->nb, c->has_merged ? "on" : (c->merged_ok ? "off (ranks differ)" : "not applicable"));
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
@@ -1835,9 +1925,14 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     drain_events(c);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
-    for (auto &B : c->blk) {
+    std::vector<Block *> all;
+    for (auto &B : c->blk) all.push_back(&B);
+    if (c->merged_ok) all.push_back(&c->merged);
+    for (Block *bp : all) {
+        Block &B = *bp;
         B.pa.release(); B.pu.release();
-        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.cv); hipFree(B.wtmp);
+        if (!B.cv_borrowed) hipFree(B.cv);
+        hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
@@ -1886,7 +1981,12 @@ int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
 
 static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
     LAUNCH(k_zero, 1, (size_t)1, c->scal + 8, NOGUARD);
-    for (auto &B : c->blk) {
+    std::vector<Block *> cones;
+    Block *S1 = solo(c);
+    if (S1 && !S1->dense_c) cones.push_back(S1);
+    else for (auto &B0 : c->blk) cones.push_back(&B0);
+    for (Block *bp : cones) {
+        Block &B = *bp;
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
@@ -1971,9 +2071,10 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
 
 static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
     const int m = c->m;
-    if (c->nb == 1 && !c->ar && c->blk[0].nrow == m && m > 0 && !c->blk[0].dense_c && c->blk[0].nc > 0) {
+    Block *S1 = solo(c);
+    if (S1 && S1->nrow == m && m > 0 && !S1->dense_c && S1->nc > 0) {
         // one cone that sees every constraint: (R,D) and (D,D) share each row visit -- 4 launches
-        Block &B = c->blk[0];
+        Block &B = *S1;
         const Shape sh = shape_for(B.r);
         const double *R = c->R + B.off, *D = c->U + B.off;
         SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rd<LG_, V2_, NS_>), nblocks_for((size_t)B.pa.ne, TPB / sh.lg), B.pa.ne, B.pa.erow,
@@ -2082,9 +2183,10 @@ int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double ou
     return 0;
 }
 int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
-    if (c->nb == 1 && !c->ar && c->blk[0].nrow == c->m && c->m > 0 && !c->blk[0].dense_c) {
+    Block *S1 = solo(c);
+    if (S1 && S1->nrow == c->m && c->m > 0 && !S1->dense_c) {
         // one cone that sees every constraint: 7 launches for the whole second half
-        Block &B = c->blk[0];
+        Block &B = *S1;
         Ring &h = c->ring[c->head];
         const int gv = grid_lbfgs(c->all_elem);
         c->ls_np = 0;
@@ -2126,7 +2228,12 @@ int lorads_hip_update_dimacs(lorads_hip_ctx *c, int32_t pair, double *err1) {
 int lorads_hip_cal_obj(lorads_hip_ctx *c, int32_t pair, double *pobj) {
     if (pair == LORADS_HIP_PAIR_UV) LAUNCH(k_average, grid1d(c->all_elem), c->all_elem, c->U, c->V, c->R, NOGUARD);
     LAUNCH(k_zero, 1, (size_t)1, c->scal + 3, NOGUARD);
-    for (auto &B : c->blk) {
+    std::vector<Block *> cones;
+    Block *S1 = solo(c);
+    if (S1 && !S1->dense_c) cones.push_back(S1);
+    else for (auto &B0 : c->blk) cones.push_back(&B0);
+    for (Block *bp : cones) {
+        Block &B = *bp;
         int g = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), NOGUARD);
         if (g) LAUNCH(k_finalize, 1, part_slot(c, 4), g, 1.0, 1, c->scal + 3, NOGUARD);
     }
@@ -2169,6 +2276,7 @@ int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
 }
 
 static void invalidate_t(lorads_hip_ctx *c) {
+    c->merged.t_uv_valid = false;
     for (auto &B : c->blk) B.t_uv_valid = false;
 }
 
@@ -2249,6 +2357,8 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
         for (int k = 0; k < c->nb; ++k) {
             Block &B = c->blk[k];
             if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
+            if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > MAXPART)
+                return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
             std::vector<double> oldm((size_t)B.n * B.r);
             if (lorads_hip_get_mat(c, whichs[a], k, oldm.data())) return 1;
             std::vector<double> nw((size_t)B.n * nr[k], 0.0);
@@ -2261,6 +2371,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
     free_factors(c);
     invalidate_t(c);
     for (int k = 0; k < c->nb; ++k) { c->blk[k].r = nr[k]; }
+    refresh_merged(c);
     if (alloc_factors(c)) return 1;
     for (int a = 0; a < 4; ++a)
         for (int k = 0; k < c->nb; ++k)

@@ -321,8 +321,11 @@ def test_fused_alm_step_equals_separate_calls(built, name, params):
             s.solve()
             res.append(s.results())
     a, b = res
-    for k in ("pObj", "dObj", "constrVio1", "pdGap", "alm_outer", "alm_inner", "admm_iter", "cg_iter", "dual_infeas_l1"):
+    for k in ("pObj", "constrVio1", "alm_outer", "alm_inner", "admm_iter", "cg_iter", "dual_infeas_l1"):
         assert a[k] == b[k], k
+    # b.lambda is summed over different workgroup partitions by the fused evaluation and by cal_dual_obj
+    for k in ("dObj", "pdGap"):
+        assert a[k] == pytest.approx(b[k], rel=1e-12, abs=1e-14), k
 
 
 def test_alm_front_and_step_function_level(built):
