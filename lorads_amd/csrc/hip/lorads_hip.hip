@@ -691,6 +691,128 @@ __global__ void k_cg_dir(size_t len, const CGState *st, int kind, const double *
     }
 }
 
+// ---- CG of MANY cones in lockstep on the merged block-diagonal cone (block-separable constraints, equal rank).
+// The gather kernels run once for all cones; what stays per cone are the scalars of CGSolve (alpha, beta, norms,
+// stopping): SegArgs maps workgroups to cones.  row0[k] = first (padded) row of cone k, a multiple of 32, so the
+// per-workgroup partials of the row kernels never straddle two cones: cone k owns tiles [row0[k]/rpw, row0[k+1]/rpw).
+// The vector kernels run over chunks of SEG_CH elements, chunk j of the launch belongs to cone vt_seg[j] and starts
+// at element vt_e0[j]; cone k owns chunk partials [vt0[k], vt0[k+1]).  State of (cone k, half) is st[2k + half].
+// phase_done[half] != 0 <=> every cone's solve of that half has finished (uniform gate for the gather kernels).
+constexpr int SEG_CH = 2048;
+struct SegArgs {
+    const int *row0, *vt0, *vt_seg;
+    const long long *vt_e0;
+    CGState *st;
+    int *phase_done;
+    int half, ncones, rpw, r;
+};
+__device__ __forceinline__ double wave_partials(const double *part, int n) { // whole wavefront, result in every lane
+    double v = 0.0;
+    for (int i = threadIdx.x & 63; i < n; i += 64) v += part[i];
+    return wave_sum(v);
+}
+// all cones finished? (after a barrier that follows the state writes)
+__device__ __forceinline__ void publish_phase_done(const SegArgs &sa, int *flag_sh) {
+    if (threadIdx.x == 0) *flag_sh = 1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < sa.ncones; k += TPB)
+        if (sa.st[2 * k + sa.half].done == 0) *flag_sh = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) sa.phase_done[sa.half] = *flag_sh;
+}
+// k_cg_init for every cone (one workgroup, one wavefront per cone in turn); the U half also re-arms the V half
+__global__ __launch_bounds__(TPB) void k_cg_init_seg(SegArgs sa, const double *__restrict__ part_rr,
+                                                     const double *__restrict__ part_b, double tol, Guard g) {
+    __shared__ int flag;
+    if (blocked(g)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < sa.ncones; k += TPB / 64) {
+        const int tb = sa.row0[k] / sa.rpw, te = sa.row0[k + 1] / sa.rpw;
+        const double a = wave_partials(part_rr + tb, te - tb), b = wave_partials(part_b + tb, te - tb);
+        if (lane == 0) {
+            CGState *st = sa.st + 2 * k + sa.half;
+            st->rr = a; st->bnorm = b; st->beta = 0.0; st->iter = 0; st->nan = 0; st->pad = 1; // pad = "started"
+            st->done = sqrt(a) / b < tol ? 2 : 0;
+            if (sa.half == 0) { sa.st[2 * k + 1].done = 0; sa.st[2 * k + 1].pad = 0; }
+        }
+    }
+    __threadfence_block();
+    if (sa.half == 0 && threadIdx.x == 0) sa.phase_done[1] = 0;
+    publish_phase_done(sa, &flag);
+}
+// k_cg_update per chunk with the alpha of the chunk's cone
+__global__ __launch_bounds__(TPB) void k_cg_update_seg(SegArgs sa, const double *__restrict__ part_pq, double *__restrict__ x,
+                                                       double *r, const double *p, const double *__restrict__ Q,
+                                                       double *__restrict__ part_rr, Guard g) {
+    __shared__ double sh[4];
+    if (blocked(g)) return;
+    const int k = sa.vt_seg[blockIdx.x];
+    const CGState *st = sa.st + 2 * k + sa.half;
+    if (st->done != 0) return;
+    const int tb = sa.row0[k] / sa.rpw, te = sa.row0[k + 1] / sa.rpw;
+    const double rr = st->rr;
+    const double pq = sum_partials(part_pq + tb, te - tb, sh);
+    const double alpha = rr / pq;
+    const long long e0 = sa.vt_e0[blockIdx.x], eend = (long long)sa.row0[k + 1] * sa.r;
+    const long long e1 = e0 + SEG_CH < eend ? e0 + SEG_CH : eend;
+    double local = 0.0;
+    for (long long i = e0 + threadIdx.x; i < e1; i += TPB) {
+        const double pv = p[i]; // p may alias r (iteration 0)
+        x[i] += alpha * pv;
+        const double rv = r[i] - alpha * Q[i];
+        r[i] = rv;
+        local += rv * rv;
+    }
+    const double t = block_sum(local, sh);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+}
+// k_cg_check for every cone (one workgroup); part: chunk partials (CHK_ITER) or row-tile partials (CHK_RESTART)
+__global__ __launch_bounds__(TPB) void k_cg_check_seg(SegArgs sa, int kind, const double *__restrict__ part, double tol,
+                                                      int maxiter, Guard g) {
+    __shared__ int flag;
+    if (blocked(g)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < sa.ncones; k += TPB / 64) {
+        CGState *st = sa.st + 2 * k + sa.half;
+        if (st->done != 0) continue; // uniform per wavefront
+        int lo, hi;
+        if (kind == CHK_ITER) { lo = sa.vt0[k]; hi = sa.vt0[k + 1]; }
+        else { lo = sa.row0[k] / sa.rpw; hi = sa.row0[k + 1] / sa.rpw; }
+        const double a = wave_partials(part + lo, hi - lo);
+        if (lane == 0) {
+            if (kind == CHK_ITER) {
+                const int it = st->iter;
+                const double rr_old = st->rr;
+                st->iter = it + 1;
+                if (a != a) st->nan = 1;
+                st->beta = a / rr_old;
+                st->rr = a;
+                if (sqrt(a) / st->bnorm < tol) st->done = 1;
+                else if (it + 1 >= maxiter) st->done = 3;
+            } else {
+                st->rr = a;
+                st->beta = 1.0;
+            }
+        }
+    }
+    __threadfence_block();
+    publish_phase_done(sa, &flag);
+}
+__global__ __launch_bounds__(TPB) void k_cg_dir_seg(SegArgs sa, int kind, const double *__restrict__ r, double *__restrict__ p,
+                                                    Guard g) {
+    if (blocked(g)) return;
+    const int k = sa.vt_seg[blockIdx.x];
+    const CGState *st = sa.st + 2 * k + sa.half;
+    if (st->done != 0) return;
+    const double beta = st->beta;
+    const long long e0 = sa.vt_e0[blockIdx.x], eend = (long long)sa.row0[k + 1] * sa.r;
+    const long long e1 = e0 + SEG_CH < eend ? e0 + SEG_CH : eend;
+    for (long long i = e0 + threadIdx.x; i < e1; i += TPB) {
+        const double rv = r[i];
+        p[i] = kind == DIR_RESTART ? rv + rv : rv + beta * p[i];
+    }
+}
+
 // ---- small vector kernels
 __global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out, Guard g) {
     if (blocked(g)) return;
@@ -1102,6 +1224,12 @@ struct lorads_hip_ctx {
     std::vector<Block> blk;
     Block merged;             // all cones as ONE block-diagonal cone (see build_merged); valid when has_merged
     bool has_merged = false;
+    std::vector<int> seg_row0_h;              // padded first row of every cone in the merged cone (+ end)
+    int *seg_row0 = nullptr, *seg_vt0 = nullptr, *seg_vt_seg = nullptr;
+    long long *seg_vt_e0 = nullptr;
+    int seg_nvt = 0;
+    int *phase_done = nullptr;                // [2]
+    int spec_b[2] = {1, 1};                   // speculated lockstep iterations of the U and V phase
     bool merged_ok = false;   // structure allows it (separable constraints, no dense C); ranks decide has_merged
     size_t all_elem = 0;
     double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
@@ -1350,9 +1478,16 @@ void block_bytes(Block &B) {
     B.bytes_cg = B.bytes_mv + 9 * F;
 }
 
+// rows of a cone inside the merged cone start at multiples of 32 (= the most rows one workgroup of a row kernel owns)
+inline int pad_rows(int n) { return (n + 31) & ~31; }
+
 int alloc_factors(lorads_hip_ctx *c) {
     c->all_elem = 0;
-    for (auto &B : c->blk) { B.off = c->all_elem; c->all_elem += (size_t)B.n * B.r; block_bytes(B); }
+    for (auto &B : c->blk) {
+        B.off = c->all_elem;
+        c->all_elem += (size_t)(c->merged_ok ? pad_rows(B.n) : B.n) * B.r; // pad rows stay zero for ever
+        block_bytes(B);
+    }
     size_t n = c->all_elem;
     double **arrs[] = {&c->R, &c->U, &c->V, &c->G, &c->cr, &c->cp, &c->cQ, &c->rhs, &c->Dtmp};
     for (auto a : arrs) {
@@ -1394,7 +1529,7 @@ int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
             if (seen[hb.row_idx[i]]) return 0; // a constraint couples two cones: the sweep order matters
             seen[hb.row_idx[i]] = 1;
         }
-        ntot += hb.n; nrow += hb.nrow; na += hb.a_ptr[hb.nrow]; nc += hb.c_nnz;
+        ntot += pad_rows(hb.n); nrow += hb.nrow; na += hb.a_ptr[hb.nrow]; nc += hb.c_nnz;
     }
     if ((int)nrow != c->m || nblocks_for(ntot, TPB / 8) > MAXPART) return 0; // partial-sum slots (refresh_merged re-checks per rank)
     std::vector<int> row_idx, a_ptr(1, 0), a_row, a_col, c_row, c_col;
@@ -1414,8 +1549,10 @@ int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
         for (int t = 0; t < hb.c_nnz; ++t) {
             c_row.push_back(hb.c_row[t] + roff); c_col.push_back(hb.c_col[t] + roff); c_val.push_back(hb.c_val[t]);
         }
-        roff += hb.n;
+        c->seg_row0_h.push_back(roff);
+        roff += pad_rows(hb.n);
     }
+    c->seg_row0_h.push_back(roff);
     lorads_hip_block mb;
     mb.n = (int)ntot; mb.rank = prob->blocks[0].rank; mb.nrow = (int)nrow; mb.row_idx = row_idx.data(); mb.a_ptr = a_ptr.data();
     mb.a_row = a_row.data(); mb.a_col = a_col.data(); mb.a_val = a_val.data(); mb.c_nnz = (int)nc; mb.c_row = c_row.data();
@@ -1431,6 +1568,8 @@ int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
         B.cv_borrowed = true;
         o += (size_t)B.nrow;
     }
+    if (upload(&c->seg_row0, c->seg_row0_h) || dalloc(&c->phase_done, (size_t)2)) return 1;
+    HC(hipMemset(c->phase_done, 0, 2 * sizeof(int)));
     c->merged_ok = true;
     return 0;
 }
@@ -1444,6 +1583,20 @@ void refresh_merged(lorads_hip_ctx *c) {
     c->merged.r = c->blk[0].r;
     c->merged.t_uv_valid = false;
     block_bytes(c->merged);
+    // chunk tables of the per-cone vector kernels (depend on the rank)
+    std::vector<int> vt0(1, 0), vt_seg;
+    std::vector<long long> vt_e0;
+    for (int k = 0; k < c->nb; ++k) {
+        const long long e0 = (long long)c->seg_row0_h[k] * c->merged.r, e1 = (long long)c->seg_row0_h[k + 1] * c->merged.r;
+        for (long long e = e0; e < e1; e += SEG_CH) { vt_seg.push_back(k); vt_e0.push_back(e); }
+        vt0.push_back((int)vt_seg.size());
+    }
+    if (vt_seg.size() > (size_t)MAXPART) return;
+    hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0);
+    c->seg_vt0 = c->seg_vt_seg = nullptr; c->seg_vt_e0 = nullptr;
+    if (upload(&c->seg_vt0, vt0) || upload(&c->seg_vt_seg, vt_seg) || upload(&c->seg_vt_e0, vt_e0)) return;
+    c->seg_nvt = (int)vt_seg.size();
+    c->spec_b[0] = c->spec_b[1] = 1;
     c->has_merged = true;
 }
 void free_factors(lorads_hip_ctx *c) {
@@ -1853,7 +2006,106 @@ int finish_sweep(lorads_hip_ctx *c, int *iters) {
     return 0;
 }
 
+// ---- lockstep sweep over all cones on the merged cone (see SegArgs).  Phase 0 = all U-solves, phase 1 = all V-solves;
+// every kernel of a phase is gated on phase_done[] -- skip when the phase is over, wait while the previous one is not.
+SegArgs seg_args(lorads_hip_ctx *c, int half) {
+    SegArgs sa;
+    sa.row0 = c->seg_row0; sa.vt0 = c->seg_vt0; sa.vt_seg = c->seg_vt_seg; sa.vt_e0 = c->seg_vt_e0; sa.st = c->st;
+    sa.phase_done = c->phase_done; sa.half = half; sa.ncones = c->nb; sa.rpw = TPB / shape_for(c->merged.r).lg; sa.r = c->merged.r;
+    return sa;
+}
+void batched_body(lorads_hip_ctx *c, int half, int k, double tol, int maxit) {
+    Block &M = c->merged;
+    const double *Vfix = half == 0 ? c->V : c->U;
+    double *x = half == 0 ? c->U : c->V;
+    double *r = c->cr, *p = k == 0 ? c->cr : c->cp, *Q = c->cQ; // p_0 = r_0
+    double *pA = part_slot(c, 0), *pC = part_slot(c, 2);
+    const Guard g{&c->phase_done[half], half ? &c->phase_done[0] : nullptr};
+    const SegArgs sa = seg_args(c, half);
+    apply_operator(c, M, Vfix, p, OP_CG, nullptr, Q, pA, g);
+    LAUNCH(k_cg_update_seg, c->seg_nvt, sa, pA, x, r, p, Q, pC, g);
+    M.t_uv_valid = false;
+    LAUNCH(k_cg_check_seg, 1, sa, (int)CHK_ITER, pC, tol, maxit, g);
+}
+void batched_tail(lorads_hip_ctx *c, int half, int k, double tol, int maxit) {
+    Block &M = c->merged;
+    const double *Vfix = half == 0 ? c->V : c->U;
+    double *x = half == 0 ? c->U : c->V;
+    const Guard g{&c->phase_done[half], half ? &c->phase_done[0] : nullptr};
+    const SegArgs sa = seg_args(c, half);
+    if (k % 20 == 0) {
+        apply_operator(c, M, Vfix, x, OP_RES, c->rhs, c->cr, part_slot(c, 0), g);
+        LAUNCH(k_cg_check_seg, 1, sa, (int)CHK_RESTART, part_slot(c, 0), tol, maxit, g);
+        LAUNCH(k_cg_dir_seg, c->seg_nvt, sa, (int)DIR_RESTART, c->cr, c->cp, g);
+    } else {
+        LAUNCH(k_cg_dir_seg, c->seg_nvt, sa, (int)DIR_BETA, c->cr, c->cp, g);
+    }
+}
+void batched_iters(lorads_hip_ctx *c, int half, int k0, int k1, double tol, int maxit) {
+    for (int k = k0; k < k1; ++k) {
+        if (k > k0) batched_tail(c, half, k - 1, tol, maxit);
+        batched_body(c, half, k, tol, maxit);
+    }
+}
+// returns the number of lockstep iterations enqueued so far for `phase` (for a later resume)
+void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, double tol, int maxit, int launched[2]) {
+    Block &M = c->merged;
+    for (int half = phase; half < 2; ++half) {
+        const double *Vfix = half == 0 ? c->V : c->U;
+        double *x = half == 0 ? c->U : c->V;
+        if (half == phase && resume >= 0) {
+            const int more = std::max(2, std::min(resume, 16));
+            if (resume > 0) batched_tail(c, half, resume - 1, tol, maxit);
+            const int k1 = std::min(resume + more, maxit);
+            batched_iters(c, half, resume, k1, tol, maxit);
+            launched[half] = k1;
+        } else {
+            const Guard front{nullptr, half ? &c->phase_done[0] : nullptr};
+            WArgs wa{};
+            wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.cv = M.cv; wa.row_idx = M.row_idx; wa.rho = rho;
+            sval(c, M.pu, true, W_ADMM, wa, front);
+            spmm(c, M, M.pu, Vfix, OP_RHS, nullptr, nullptr, rho, c->rhs, part_slot(c, 1), front);
+            apply_operator(c, M, Vfix, x, OP_RES, c->rhs, c->cr, part_slot(c, 0), front);
+            LAUNCH(k_cg_init_seg, 1, seg_args(c, half), part_slot(c, 0), part_slot(c, 1), tol, front);
+            const int k1 = std::min(std::max(c->spec_b[half], 0), maxit);
+            batched_iters(c, half, 0, k1, tol, maxit);
+            launched[half] = k1;
+        }
+        // constrVal <- A(sym(U V^T)), constrValSum += new - old for every cone at once
+        constr_val(c, M, c->U, c->V, 1.0, M.cv, CV_DELTA, c->csum, Guard{nullptr, &c->phase_done[half]});
+    }
+}
+int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
+    int phase = 0, resume = -1, launched[2] = {0, 0};
+    for (;;) {
+        enqueue_batched(c, phase, resume, rho, tol, maxit, launched);
+        if (with_eval && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
+        if (read_states(c)) return 1;
+        bool u_done = true, v_done = true;
+        for (int k = 0; k < c->nb; ++k) {
+            u_done = u_done && c->h_st[2 * k].done != 0;
+            v_done = v_done && c->h_st[2 * k + 1].pad == 1 && c->h_st[2 * k + 1].done != 0;
+        }
+        if (u_done && v_done) break;
+        c->n_resume++;
+        c->merged.t_uv_valid = false; // kernels after the miss did not run: recompute
+        if (!u_done) { phase = 0; resume = launched[0]; }
+        else { phase = 1; resume = c->h_st[1].pad == 1 ? launched[1] : -1; }
+    }
+    // speculation for the next ADMM iteration: what the slowest cone needed
+    for (int half = 0; half < 2; ++half) {
+        int mx = 0;
+        for (int k = 0; k < c->nb; ++k) {
+            const CGState &h = c->h_st[2 * k + half];
+            if (h.done != 2) mx = std::max(mx, h.iter);
+        }
+        c->spec_b[half] = mx;
+    }
+    return 0;
+}
+
 int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
+    if (c->has_merged && !c->ar && !getenv("LORADS_NO_BATCH")) return run_sweep_batched(c, rho, tol, maxit, with_eval);
     int first = 0, resume = -1;
     // every stage starts "not finished": a stage whose predecessor misses its speculation must stay
     // blocked (and block its successors) instead of seeing last iteration's done word
@@ -1939,6 +2191,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     free_factors(c);
     hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl);
     hipFree(c->ring_ab);
+    hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
