@@ -159,6 +159,22 @@ def blockdiag_maxcut(nblk, n_k, edges_k, seed0):
     return dict(m=nblk * n_k, blocks=[n_k] * nblk, b=np.ones(nblk * n_k), entries=ent)
 
 
+def block_diag(subs):
+    """Independent single-block problems side by side: block-separable constraints (each A_i lives in one
+    block), blocks of different size and kind."""
+    ent, blocks, bs = [], [], []
+    moff = 0
+    for k, sub in enumerate(subs):
+        assert len(sub["blocks"]) == 1
+        for mat, _, i, j, v in sub["entries"]:
+            ent.append((0 if mat == 0 else mat + moff, k + 1, i, j, v))
+        moff += sub["m"]
+        blocks.append(sub["blocks"][0])
+        bs.append(np.asarray(sub["b"], dtype=np.float64))
+    ent.sort(key=lambda e: (e[0], e[1]))
+    return dict(m=moff, blocks=blocks, b=np.concatenate(bs), entries=ent)
+
+
 def coupled_blocks(nblk, n_k, m, seed, n_diag=2, n_off=4, r0=3, c_edges=None):
     """Block-diagonal SDP whose constraints COUPLE the blocks: every A_i has entries in every
     block (dense-cone branch per block; Gauss-Seidel != Jacobi)."""
@@ -223,6 +239,9 @@ NAMED = {
     "coupled3x70": lambda: coupled_blocks(3, 70, 30, 3100, n_diag=1, n_off=2, r0=2, c_edges=60),
     "densec40": lambda: randsparse(40, 20, 777, n_diag=1, n_off=2, r0=2, dense_c=True),
     "matcomp60": lambda: matcomp(30, 30, 200, 3, 50),
+    # separable cones of different size and kind, equal rank 9: the lockstep (batched) sweep with row padding
+    "mix4": lambda: block_diag([maxcut(60, 90, 61), randsparse(70, 45, 62, c_edges=90, n_diag=2, n_off=3, r0=3),
+                                maxcut(66, 100, 63), matcomp(35, 33, 220, 3, 64)]),
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
     # timing / log-level instances
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like

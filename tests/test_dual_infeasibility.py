@@ -12,7 +12,7 @@ import pytest
 from tests import common
 from lorads_amd import host, instances
 
-NAMES = ["maxcut100", "rand120", "blk4x60", "theta30", "densec40", "matcomp60", "coupled3x70"]
+NAMES = ["maxcut100", "rand120", "blk4x60", "theta30", "densec40", "matcomp60", "coupled3x70", "mix4"]
 
 
 def _exact(prob, lam):

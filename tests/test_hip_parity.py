@@ -12,7 +12,7 @@ from tests import common
 
 pytestmark = pytest.mark.gpu
 
-TRACE_NAMES = ["maxcut100", "theta30", "rand120", "blk4x60", "coupled3x70", "densec40", "matcomp60"]
+TRACE_NAMES = ["maxcut100", "theta30", "rand120", "blk4x60", "coupled3x70", "densec40", "matcomp60", "mix4"]
 
 
 @pytest.mark.parametrize("name", TRACE_NAMES)
@@ -362,3 +362,48 @@ def test_alm_front_and_step_function_level(built):
             out.append(rec)
     for x, y in zip(*out):
         assert x == y
+
+
+@pytest.mark.parametrize("name", ["blk4x60", "mix4"])
+def test_lockstep_sweep_equals_cone_by_cone(built, name):
+    """Block-separable cones of equal rank are swept in lockstep on the merged cone (one launch chain for all cones,
+    per-cone CG scalars).  Against the cone-by-cone sweep (LORADS_NO_BATCH) on the same state: same CG iteration
+    counts per ADMM iteration, factors equal to rounding (the per-cone partial sums are taken in another order)."""
+    g = common.golden_trace(name)
+    path = common.instance_path(name)
+    sessions = [common.hip_session(path), common.hip_session(path)]
+    try:
+        rank_warm = [int(x) for x in g["rank_warm"]]
+        for s in sessions:
+            if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                s.be.resize_rank(rank_warm)
+            for k in range(s.nblk):
+                n, r = s.block_shape(k)
+                s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+            s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+            s.be.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+            s.be.cal_obj(host.PAIR_UV)
+            s.be.update_dimacs(host.PAIR_UV)
+        a, b = sessions
+        rho = float(g["admm_rho"][0])
+        for it, tol in enumerate([1e-8, 1e-8, 1e-12, 1e-6, 1e-10, 1e-9]):
+            os.environ.pop("LORADS_NO_BATCH", None)
+            ca, pa, da, ea = a.be.admm_step(rho, tol, 800)
+            os.environ["LORADS_NO_BATCH"] = "1"
+            try:
+                cb, pb, db, eb = b.be.admm_step(rho, tol, 800)
+            finally:
+                os.environ.pop("LORADS_NO_BATCH", None)
+            assert ca == cb, (it, ca, cb)
+            assert pa == pytest.approx(pb, rel=1e-11) and da == pytest.approx(db, rel=1e-11)
+            assert ea == pytest.approx(eb, rel=1e-7, abs=1e-14)
+            for k in range(a.nblk):
+                for which in (host.MAT_U, host.MAT_V):
+                    x, y = a.be.get_mat(which, k), b.be.get_mat(which, k)
+                    assert np.allclose(x, y, rtol=0, atol=1e-10 * max(1.0, np.abs(y).max())), (it, k, which)
+            a.be.update_dual_var(rho)
+            b.be.update_dual_var(rho)
+    finally:
+        for s in sessions:
+            s.close()
