@@ -1531,7 +1531,9 @@ int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
         }
         ntot += pad_rows(hb.n); nrow += hb.nrow; na += hb.a_ptr[hb.nrow]; nc += hb.c_nnz;
     }
-    if ((int)nrow != c->m || nblocks_for(ntot, TPB / 8) > MAXPART) return 0; // partial-sum slots (refresh_merged re-checks per rank)
+    // (a sharded context sees only its own cones' constraints: nrow < m is fine, the single-cone shortcuts that need
+    // every constraint check nrow == m themselves)
+    if (nblocks_for(ntot, TPB / 8) > MAXPART) return 0; // partial-sum slots (refresh_merged re-checks per rank)
     std::vector<int> row_idx, a_ptr(1, 0), a_row, a_col, c_row, c_col;
     std::vector<double> a_val, c_val;
     row_idx.reserve(nrow); a_row.reserve(na); a_col.reserve(na); a_val.reserve(na);
@@ -2079,7 +2081,9 @@ int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool
     int phase = 0, resume = -1, launched[2] = {0, 0};
     for (;;) {
         enqueue_batched(c, phase, resume, rho, tol, maxit, launched);
-        if (with_eval && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
+        // the evaluation rides along speculatively -- except with sharded cones: its all-reduce must be issued exactly
+        // once per ADMM iteration on EVERY rank, whatever each rank's own speculation did (see run_sweep)
+        if (with_eval && !c->ar && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
         if (read_states(c)) return 1;
         bool u_done = true, v_done = true;
         for (int k = 0; k < c->nb; ++k) {
@@ -2101,18 +2105,26 @@ int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool
         }
         c->spec_b[half] = mx;
     }
+    if (with_eval && c->ar) {
+        if (enqueue_eval(c, LORADS_HIP_PAIR_UV, nullptr)) return 1;
+        if (read_states(c)) return 1;
+    }
     return 0;
 }
 
 int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
-    if (c->has_merged && !c->ar && !getenv("LORADS_NO_BATCH")) return run_sweep_batched(c, rho, tol, maxit, with_eval);
+    // (no cross-rank sum inside the sweep: with sharded cones the lockstep form works unchanged)
+    if (c->has_merged && !getenv("LORADS_NO_BATCH")) return run_sweep_batched(c, rho, tol, maxit, with_eval);
     int first = 0, resume = -1;
     // every stage starts "not finished": a stage whose predecessor misses its speculation must stay
     // blocked (and block its successors) instead of seeing last iteration's done word
     if (2 * c->nb - 1 > TPB) HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * (size_t)(2 * c->nb), c->stream));
     for (;;) {
         enqueue_sweep(c, first, resume, rho, tol, maxit);
-        if (with_eval && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
+        // With sharded cones the evaluation contains the all-reduce, a collective every rank must enter the same
+        // number of times; a rank that missed its speculation would enter it twice.  So it is issued after the
+        // sweep has finished (one more host synchronisation per ADMM iteration in the multi-GPU case).
+        if (with_eval && !c->ar && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
         if (read_states(c)) return 1;
         const int stg = first_unfinished(c, first);
         if (stg < 0) break;
@@ -2120,6 +2132,10 @@ int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_ev
         resume = c->h_st[stg].iter;
         c->n_resume++;
         for (auto &B : c->blk) B.t_uv_valid = false; // kernels after the miss did not run: recompute
+    }
+    if (with_eval && c->ar) {
+        if (enqueue_eval(c, LORADS_HIP_PAIR_UV, nullptr)) return 1;
+        if (read_states(c)) return 1;
     }
     return 0;
 }

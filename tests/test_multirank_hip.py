@@ -1,0 +1,82 @@
+"""N > 1 on the device path: two processes (gloo rendezvous, both on cuda:0 -- the box has one GPU) each hold half
+of the cones of a block-diagonal problem in their own HIP context; the cross-rank sums go through the all-reduce
+hook on DEVICE buffers exactly as bench.py --gpus N does with RCCL.  With two cones per rank the lockstep sweep
+runs inside each rank.  Compared with the single-process device run and the reference's golden solve."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, params, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    from tests import common
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    s = common.hip_session(common.instance_path(name), world=world, rank=rank, **params)
+    try:
+        mode = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
+        s.solve()
+        r = s.results()
+        r["nblk_local"] = s.nblk
+        r["mode"] = mode
+        q.put((rank, r))
+    finally:
+        s.close()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name,params", [("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2)),
+                                         ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7))])
+def test_two_ranks_on_device_match_single_process(built, name, params):
+    from tests import common
+    with common.hip_session(common.instance_path(name), **params) as s:
+        s.solve()
+        ref = s.results()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, params, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        out = dict(q.get(timeout=150) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # a rank stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.kill()
+    a, b = out[0], out[1]
+    assert a["nblk_local"] == b["nblk_local"] == 2
+    for k in ("pObj", "dObj", "constrVio1", "pdGap", "admm_iter", "alm_inner"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    # block-separable constraints: Jacobi across ranks == Gauss-Seidel; only summation orders differ
+    gold = [g for g in common.golden_solves() if g["instance"] == name and "1" in g["flags"][1:2]]
+    assert a["pObj"] == pytest.approx(ref["pObj"], rel=2e-6)
+    assert a["dObj"] == pytest.approx(ref["dObj"], rel=2e-6)
+    assert a["constrVio1"] <= 1e-5 and a["pdGap"] <= 1e-5
+    assert gold, "no reference solve of this instance in tests/golden/solve.json"
+    e = gold[-1]  # the reference's own run of the same file (possibly at a tighter phase2Tol): converged objective
+    gap = abs(e["pObj"] - e["dObj"]) / (1 + abs(e["pObj"]) + abs(e["dObj"]))
+    assert abs(a["pObj"] - e["pObj"]) <= max(2e-5, 10 * gap) * (1 + abs(e["pObj"]))
