@@ -813,6 +813,15 @@ __global__ __launch_bounds__(TPB) void k_cg_dir_seg(SegArgs sa, int kind, const 
     }
 }
 
+// 1.0 when the gate word says "not finished" (this rank missed its speculation), else 0.0 -- rides on the all-reduce
+__global__ void k_miss_flag(const int *need, double *out) { *out = (need && *need == 0) ? 1.0 : 0.0; }
+// constrValSum <- the all-reduced staging vector, unless some rank reported a miss (stage[m+1] = number of such ranks):
+// then every rank keeps its constrValSum -- the unfinished sweeps still need it -- and the evaluation is repeated
+__global__ void k_commit_csum(int m, const double *__restrict__ stage, double *__restrict__ csum) {
+    if (stage[m + 1] != 0.0) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) csum[i] = stage[i];
+}
+
 // ---- small vector kernels
 __global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out, Guard g) {
     if (blocked(g)) return;
@@ -1235,6 +1244,7 @@ struct lorads_hip_ctx {
     double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
     double *cr = nullptr, *cp = nullptr, *cQ = nullptr, *rhs = nullptr; // flat CG vectors
     double *Dtmp = nullptr;
+    double *cstage = nullptr; // m+2: [local constrValSum | objective part | miss flag] on its way through the all-reduce
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
     double *part = nullptr;   // NSLOT x MAXPART partial sums
     int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
@@ -1938,7 +1948,10 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
     const bool single = (S1 && S1->nrow == c->m) || (c->nb == 1 && c->blk[0].nrow == c->m);
     const bool fold_res = single && !c->ar && c->m > 0; // the constraint-value kernel also delivers the residual partials
     c->ls_np = 0;
-    if (!single) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, c->csum, g);
+    // sharded cones: the local sums go to a staging vector, are all-reduced there and committed to constrValSum only
+    // if no rank reported a speculation miss (an unfinished sweep still needs the old constrValSum)
+    double *dst = c->ar ? c->cstage : c->csum;
+    if (!single || c->ar) LAUNCH(k_zero, grid1d((size_t)c->m), (size_t)c->m, dst, g);
     bool first_obj = true;
     const bool fold_obj = (c->nb == 1 || S1) && !c->ar; // the final kernel sums the objective partials itself
     int nobj = 0, nres = 0;
@@ -1953,7 +1966,7 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
             LAUNCH(k_cv_res, nres, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.cv, B.row_idx, c->csum, c->b, c->lambda, part_slot(c, 8),
                    part_slot(c, 9), g);
         } else {
-            constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, single ? CV_SET : CV_ADD, c->csum, g);
+            constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, (single && !c->ar) ? CV_SET : CV_ADD, dst, g);
         }
         if (!with_obj) continue; // DIMACS refresh alone (lorads_alg_common.c:250-290) does not touch the objective
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
@@ -1961,10 +1974,13 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
         if (go) { LAUNCH(k_finalize, 1, part_slot(c, 4), go, 1.0, first_obj ? 0 : 1, c->scal + 2, g); first_obj = false; }
     }
     if (with_obj && first_obj && !(fold_obj && nobj > 0)) LAUNCH(k_zero, 1, (size_t)1, c->scal + 2, g);
-    if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part] per evaluation
-        HC(hipMemcpyAsync(c->csum + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        if (allreduce_dev(c, c->csum, c->m + 1)) return 1;
-        HC(hipMemcpyAsync(c->scal + 2, c->csum + c->m, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (c->ar) { // sharded cones: ONE all-reduce of [constrValSum | objective part | "I missed my speculation"]
+        HC(hipMemcpyAsync(dst + c->m, c->scal + 2, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_miss_flag, dim3(1), dim3(1), 0, c->stream, need, dst + c->m + 1);
+        if (allreduce_dev(c, dst, c->m + 2)) return 1;
+        LAUNCH(k_commit_csum, std::max(1, std::min(grid1d((size_t)c->m), 256)), c->m, dst, c->csum);
+        HC(hipMemcpyAsync(c->scal + 2, dst + c->m, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HC(hipMemcpyAsync(c->scal + 5, dst + c->m + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     if (!fold_res) {
         nres = std::min(grid1d((size_t)c->m), 1024);
@@ -2079,12 +2095,15 @@ void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, doubl
 }
 int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
     int phase = 0, resume = -1, launched[2] = {0, 0};
+    bool first_pass = true, any_missed = false;
     for (;;) {
         enqueue_batched(c, phase, resume, rho, tol, maxit, launched);
-        // the evaluation rides along speculatively -- except with sharded cones: its all-reduce must be issued exactly
-        // once per ADMM iteration on EVERY rank, whatever each rank's own speculation did (see run_sweep)
-        if (with_eval && !c->ar && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
+        // the evaluation rides along speculatively; with sharded cones only in the first pass (see run_sweep)
+        const bool eval_now = with_eval && (!c->ar || first_pass);
+        if (eval_now && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
         if (read_states(c)) return 1;
+        if (eval_now && c->ar) any_missed = c->h_scal[5] > 0.5;
+        first_pass = false;
         bool u_done = true, v_done = true;
         for (int k = 0; k < c->nb; ++k) {
             u_done = u_done && c->h_st[2 * k].done != 0;
@@ -2105,7 +2124,7 @@ int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool
         }
         c->spec_b[half] = mx;
     }
-    if (with_eval && c->ar) {
+    if (with_eval && c->ar && any_missed) { // some rank missed: every rank evaluates again, now with finished sweeps
         if (enqueue_eval(c, LORADS_HIP_PAIR_UV, nullptr)) return 1;
         if (read_states(c)) return 1;
     }
@@ -2116,16 +2135,21 @@ int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_ev
     // (no cross-rank sum inside the sweep: with sharded cones the lockstep form works unchanged)
     if (c->has_merged && !getenv("LORADS_NO_BATCH")) return run_sweep_batched(c, rho, tol, maxit, with_eval);
     int first = 0, resume = -1;
+    bool first_pass = true, any_missed = false;
     // every stage starts "not finished": a stage whose predecessor misses its speculation must stay
     // blocked (and block its successors) instead of seeing last iteration's done word
     if (2 * c->nb - 1 > TPB) HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * (size_t)(2 * c->nb), c->stream));
     for (;;) {
         enqueue_sweep(c, first, resume, rho, tol, maxit);
         // With sharded cones the evaluation contains the all-reduce, a collective every rank must enter the same
-        // number of times; a rank that missed its speculation would enter it twice.  So it is issued after the
-        // sweep has finished (one more host synchronisation per ADMM iteration in the multi-GPU case).
-        if (with_eval && !c->ar && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
+        // number of times, whatever its own speculation did.  Every rank enters it once in the first pass, and the
+        // reduced vector carries one extra word: how many ranks missed.  If any did, every rank finishes its sweep
+        // and all enter the collective once more.  No miss anywhere (the common case): one host synchronisation.
+        const bool eval_now = with_eval && (!c->ar || first_pass);
+        if (eval_now && enqueue_eval(c, LORADS_HIP_PAIR_UV, c->nb ? &c->st[2 * c->nb - 1].done : nullptr)) return 1;
         if (read_states(c)) return 1;
+        if (eval_now && c->ar) any_missed = c->h_scal[5] > 0.5;
+        first_pass = false;
         const int stg = first_unfinished(c, first);
         if (stg < 0) break;
         first = stg;
@@ -2133,7 +2157,7 @@ int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_ev
         c->n_resume++;
         for (auto &B : c->blk) B.t_uv_valid = false; // kernels after the miss did not run: recompute
     }
-    if (with_eval && c->ar) {
+    if (with_eval && c->ar && any_missed) {
         if (enqueue_eval(c, LORADS_HIP_PAIR_UV, nullptr)) return 1;
         if (read_states(c)) return 1;
     }
@@ -2166,6 +2190,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
+        dalloc(&c->cstage, (size_t)c->m + 2) ||
         dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
         dalloc(&c->ring_ab, (size_t)2 * c->L)) {
@@ -2205,6 +2230,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         hipFree(B.g_val);
     }
     free_factors(c);
+    hipFree(c->cstage);
     hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
