@@ -282,7 +282,13 @@ class Session:
 
     def set_params(self, **kw):
         for k, v in kw.items():
-            if self.lib.lrd_session_set_param(self.h, k.encode(), repr(v).encode() if not isinstance(v, str) else v.encode()):
+            if isinstance(v, (bool, np.bool_)) or (isinstance(v, (int, np.integer)) and not isinstance(v, bool)):
+                txt = str(int(v))
+            elif isinstance(v, (float, np.floating)):
+                txt = repr(float(v))  # repr(np.float64(x)) is not a number literal
+            else:
+                txt = str(v)
+            if self.lib.lrd_session_set_param(self.h, k.encode(), txt.encode()):
                 raise KeyError("unknown parameter %s" % k)
 
     def prepare(self, world=1, rank=0):

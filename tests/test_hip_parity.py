@@ -407,3 +407,76 @@ def test_lockstep_sweep_equals_cone_by_cone(built, name):
     finally:
         for s in sessions:
             s.close()
+
+
+@pytest.mark.parametrize("name,ranks", [("rand120", [1, 2, 3, 7, 16, 33, 64, 66, 100, 129, 130, 200, 300]),
+                                        ("maxcut100", [1, 5, 40, 65, 128, 131, 258]),
+                                        ("matcomp60", [1, 4, 30, 67, 140]),
+                                        ("blk4x60", [1, 6, 31, 70, 133]),
+                                        ("densec40", [1, 2, 17, 48, 127, 128])])
+def test_every_rank_shape_vs_oracle(built, name, ranks):
+    """The row kernels are instantiated per (lanes per row, 16-byte loads, column steps): r even <= 128 -> 8 lanes x
+    double2, odd or larger r -> 8 / 32 / 64 lanes x double.  Every shape, on the general (Gram), diagonal, single-entry,
+    merged multi-cone and dense-C (MFMA, r <= 128) operator paths, function by function against the oracle from the
+    same random factors."""
+    path = common.instance_path(name)
+    for r in ranks:
+        # the rank rule gives ceil(timesLogRank * ln n) (capped): aim at r from below, grow to r if the cap bites
+        with common.oracle_session(path) as probe:
+            n0 = probe.block_shape(0)[0]
+        hs, os_ = _pair(path, timesLogRank=float((r - 0.5) / np.log(n0)))
+        try:
+            nb = hs.nblk
+            cur = [hs.block_shape(k)[1] for k in range(nb)]
+            assert max(cur) <= r, (cur, r)
+            rng = np.random.default_rng(1000 + r)
+            lam = 0.1 * rng.standard_normal(hs.m)
+            if cur != [r] * nb:
+                for s in (hs, os_):
+                    s.be.resize_rank([r] * nb)
+            rr = [hs.block_shape(k)[1] for k in range(nb)]
+            Rs = [rng.standard_normal((hs.block_shape(k)[0], rr[k])) / np.sqrt(hs.block_shape(k)[0]) for k in range(nb)]
+            for s in (hs, os_):
+                for k in range(nb):
+                    s.be.set_mat(host.MAT_R, k, Rs[k])
+                s.be.set_vec(host.VEC_LAMBDA, lam)
+            rho = 0.7
+            vals = []
+            for s in (hs, os_):
+                be = s.be
+                be.init_constr(host.PAIR_RR)
+                lag = be.alm_cal_grad(rho)
+                be.lbfgs_direction(0)
+                p1, p2 = be.alm_q12p12()
+                kk = be.alm_linesearch_coeffs(rho, p1, p2)
+                tau, _ = common.linesearch_tau(kk)
+                be.set_y_as_neg_grad()
+                be.alm_update_var(min(tau, 0.5))
+                lag2 = be.alm_cal_grad(rho)
+                be.set_lbfgs_his_two(min(tau, 0.5))
+                e1 = be.update_dimacs(host.PAIR_RR)
+                be.lbfgs_direction(1)
+                D = [be.get_mat(host.MAT_U, k) for k in range(nb)]
+                po = be.cal_obj(host.PAIR_RR)
+                be.alm_to_admm()
+                be.init_constr(host.PAIR_UV)
+                it = be.admm_update_var(1.5, 1e-9, 800)
+                U = [be.get_mat(host.MAT_U, k) for k in range(nb)]
+                V = [be.get_mat(host.MAT_V, k) for k in range(nb)]
+                e2 = be.update_dimacs(host.PAIR_UV)
+                vals.append((lag, p1, p2, kk, lag2, e1, D, po, it, U, V, e2))
+            a, b = vals
+            assert np.isclose(a[0], b[0], rtol=1e-10), (r, "lag")
+            assert np.isclose(a[1], b[1], rtol=1e-9, atol=1e-9 * abs(b[2])) and np.isclose(a[2], b[2], rtol=1e-9), (r, "p12")
+            assert np.allclose(a[3], b[3], rtol=1e-8, atol=1e-9 * max(abs(x) for x in b[3])), (r, "coef")
+            assert np.isclose(a[4], b[4], rtol=1e-9) and np.isclose(a[5], b[5], rtol=1e-9), (r, "lag2/err")
+            assert np.isclose(a[7], b[7], rtol=1e-10), (r, "obj")
+            assert abs(a[8] - b[8]) <= max(2, 0.03 * b[8]), (r, "cg iterations", a[8], b[8])
+            for k in range(nb):
+                assert np.allclose(a[6][k], b[6][k], rtol=0, atol=1e-9 * np.abs(b[6][k]).max()), (r, k, "D")
+                assert np.allclose(a[9][k], b[9][k], rtol=0, atol=2e-6 * np.abs(b[9][k]).max()), (r, k, "U")
+                assert np.allclose(a[10][k], b[10][k], rtol=0, atol=2e-6 * np.abs(b[10][k]).max()), (r, k, "V")
+            assert np.isclose(a[11], b[11], rtol=1e-4, atol=1e-9), (r, "err2")
+        finally:
+            hs.close()
+            os_.close()
