@@ -65,6 +65,11 @@ typedef struct {
     int *a_pidx; /* [a_ptr[nrow]] position of each A entry in the pattern (nnzIdx2ResIdx) */
     int *c_pidx; /* [c_nnz] */
     int rank, rank_max; /* data/lorads_solver.c:290-319 */
+    /* 1: this "cone" is the LP block of the file (one diagonal block, last; io/lorads_file_io.c:120-124,260-269):
+     * n = number of LP columns, every entry diagonal, rank fixed at 1 -- x_i = r_i^2 (u_i v_i).  In phase 1 and in
+     * every evaluation it behaves as a diagonal cone (data/lorads_lp_conic.c:172-217); only the ADMM update differs:
+     * column by column in closed form (lorads_alg/lorads_admm.c:595-629, lorads_alg_common.c:225-248). */
+    int is_lp;
     int global_id;      /* index of this cone in the file (multi-GPU sharding keeps a subset) */
 } lrd_block;
 
@@ -74,7 +79,8 @@ typedef struct {
     int nblk;  /* blocks held by THIS process */
     lrd_block *blk;
     int nblk_global;
-    int sum_dims_global; /* sum of all block dims, for rho0 = 1/sqrt(.) (data/lorads_solver.c:1155-1162) */
+    int nsdp_global;     /* SDP cones of the file (ASolver->nCones): the LP block is not one of them */
+    int sum_dims_global; /* sum of all SDP block dims, for rho0 = 1/sqrt(.) (data/lorads_solver.c:1155-1162) */
     /* norms (data/lorads_solver.c:1054-1073), over ALL blocks of the file */
     double cObjNrm1, cObjNrm2, cObjNrmInf, bNrm1, bNrm2, bNrmInf;
 } lrd_problem;

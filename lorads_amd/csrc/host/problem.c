@@ -75,8 +75,8 @@ static int block_presolve(lrd_block *b, int m) {
     const int na = b->a_ptr[b->nrow];
     b->cone_sparse = !((double)b->nrow > 0.3 * (double)m);
     int dense = 0;
-    if (n < 20) dense = 1;
-    if (!dense) {
+    if (n < 20 && !b->is_lp) dense = 1;
+    if (!dense && !b->is_lp) {
         if ((double)b->c_nnz > 0.1 * (double)npack) dense = 1;
         for (int i = 0; i < b->nrow && !dense; ++i)
             if ((double)(b->a_ptr[i + 1] - b->a_ptr[i]) > 0.1 * (double)npack) dense = 1;
@@ -91,7 +91,7 @@ static int block_presolve(lrd_block *b, int m) {
         qsort(u, (size_t)tot, sizeof(pos_t), pos_cmp);
         for (int k = 0; k < tot; ++k)
             if (k == 0 || u[k].row != u[k - 1].row || u[k].col != u[k - 1].col) u[np++] = u[k];
-        if ((double)np / (double)npack >= 0.1) { dense = 1; free(u); u = NULL; }
+        if ((double)np / (double)npack >= 0.1 && !b->is_lp) { dense = 1; free(u); u = NULL; }
     }
     b->dense_mode = dense;
     free(b->p_row); free(b->p_col); free(b->a_pidx); free(b->c_pidx);
@@ -126,12 +126,16 @@ static void problem_norms(lrd_problem *p) {
     double n1 = 0, n2 = 0, ninf = 0;
     for (int k = 0; k < p->nblk; ++k) {
         const lrd_block *b = &p->blk[k];
+        double lp1 = 0;
         for (int t = 0; t < b->c_nnz; ++t) {
             double a = fabs(b->c_val[t]);
-            if (b->c_row[t] == b->c_col[t]) { n1 += a; n2 += a * a; }
+            if (b->is_lp) { n1 += a; lp1 += a; }
+            else if (b->c_row[t] == b->c_col[t]) { n1 += a; n2 += a * a; }
             else { n1 += 2 * a; n2 += 2 * a * a; }
             if (a > ninf) ninf = a;
         }
+        /* the LP cone reports (||c||_1)^2 as its "nrm2 square" (data/lorads_lp_conic.c:128-133) -- kept */
+        if (b->is_lp) n2 += lp1 * lp1;
     }
     p->cObjNrm1 = n1; p->cObjNrm2 = sqrt(n2); p->cObjNrmInf = ninf;
     double b1 = 0, b2 = 0, binf = 0;
@@ -153,15 +157,21 @@ static int build_problem(int m, const double *bvec, int nblk, const int *dims, e
     p->nblk = p->nblk_global = nblk;
     p->blk = (lrd_block *)calloc((size_t)nblk, sizeof(lrd_block));
     p->sum_dims_global = 0;
-    for (int k = 0; k < nblk; ++k) { p->blk[k].n = dims[k]; p->blk[k].global_id = k; p->sum_dims_global += dims[k]; }
+    for (int k = 0; k < nblk; ++k) {
+        p->blk[k].is_lp = dims[k] < 0; /* negative dimension = the diagonal (LP) block */
+        p->blk[k].n = dims[k] < 0 ? -dims[k] : dims[k];
+        p->blk[k].global_id = k;
+        if (!p->blk[k].is_lp) { p->sum_dims_global += p->blk[k].n; p->nsdp_global += 1; }
+    }
     /* normalise: drop tiny, lower triangle, negate F0 */
     int64_t w = 0;
     for (int64_t t = 0; t < ne; ++t) {
         ent_t x = e[t];
         if (fabs(x.val) < 1e-12) continue;
         if (x.blk < 0 || x.blk >= nblk || x.mat < 0 || x.mat > m) { lrd_problem_free(p); return 2; }
+        if (p->blk[x.blk].is_lp) x.col = x.row; /* the reference keys LP entries by their row index only (:264) */
         if (x.row < x.col) { int tmp = x.row; x.row = x.col; x.col = tmp; }
-        if (x.col < 0 || x.row >= dims[x.blk]) { lrd_problem_free(p); return 2; }
+        if (x.col < 0 || x.row >= p->blk[x.blk].n) { lrd_problem_free(p); return 2; }
         if (x.mat == 0) x.val = -x.val;
         x.seq = t;
         e[w++] = x;
@@ -272,8 +282,8 @@ int lrd_read_sdpa(const char *fname, lrd_problem **out) {
           char *s = ln;
           while (got < nblk && next_number(&s, &v)) dims[got++] = (int)v;
       } }
-    for (int k = 0; k < nblk; ++k)
-        if (dims[k] <= 0) { rc = 4; goto done; } /* LP (diagonal) block: out of scope, SURVEY.md 2 #12 */
+    for (int k = 0; k < nblk; ++k) /* one diagonal (LP) block, and only at the end, as the reference (:120-124) */
+        if (dims[k] == 0 || (dims[k] < 0 && k != nblk - 1)) { rc = 4; goto done; }
     b = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
     { int got = 0;
       while (got < m) {
@@ -314,12 +324,13 @@ void lrd_problem_select(lrd_problem *p, const int *keep) {
 void lrd_determine_rank(lrd_problem *p, double times) {
     for (int k = 0; k < p->nblk; ++k) {
         lrd_block *b = &p->blk[k];
+        if (b->is_lp) { b->rank = b->rank_max = 1; continue; }
         int nnz_rows = b->nrow;
         int cap = (int)sqrt(2.0 * nnz_rows) + 1;
         if (cap > b->n) cap = b->n;
         int r;
         if (times <= 1e-6) r = cap;
-        else if (nnz_rows / b->n >= 20 && b->n <= 400 && p->nblk_global <= 3) r = cap;
+        else if (nnz_rows / b->n >= 20 && b->n <= 400 && p->nsdp_global <= 3) r = cap;
         else {
             double lr = ceil(times * log((double)b->n));
             r = (int)(lr < (double)cap ? lr : (double)cap);

@@ -118,7 +118,7 @@ int lrd_solver_init(lrd_solver *s, lrd_problem *prob, lrd_backend *be, const lrd
     d->l_inf_dual_infeasibility = d->l_inf_primal_infeasibility = 1e30;
     d->l_2_dual_infeasibility = d->l_2_primal_infeasibility = 1e30;
     d->rho = rho;
-    d->nBlks = prob->nblk_global;
+    d->nBlks = prob->nsdp_global > 0 ? prob->nsdp_global : 1;
     s->scaleObjHis = 1.0;
     s->max_alm_sub_iter = 5000;
     s->status = LRD_UNKNOWN;
@@ -370,7 +370,7 @@ restart:
         }
         alm_log(par, st, lrd_time() - t_ori);
         if (lrd_time() - t_start >= par->timeSecLimit) goto print_and_exit;
-        if (rank_flag >= rank_thres && !is_rank_max && (!reopt || s->prob->nblk_global <= 10)) {
+        if (rank_flag >= rank_thres && !is_rank_max && (!reopt || s->prob->nsdp_global <= 10)) {
             rank_flag = 0;
             if (k - last_outer_start >= 2) {
                 if (par->verbose) printf("increase the rank, factor:%f.\n", rank_factor);

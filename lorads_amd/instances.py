@@ -175,6 +175,37 @@ def block_diag(subs):
     return dict(m=moff, blocks=blocks, b=np.concatenate(bs), entries=ent)
 
 
+def sdp_lp(n, n_edges, n_extra, seed):
+    """SDP block + LP block (SDPA: a last block of negative dimension, diagonal entries only).
+    max <L/4, X> - c's  s.t.  X_ii + s_i = 1 (one slack column per row: X_ii <= 1), plus n_extra LP columns that
+    each sit in two neighbouring rows -- they couple rows, so the column-by-column ADMM update of the LP block has
+    real Gauss-Seidel dependencies.  All LP costs positive (bounded)."""
+    rng = np.random.default_rng(seed)
+    edges = _rand_edges(n, n_edges, rng)
+    deg = np.zeros(n)
+    np.add.at(deg, edges[:, 0], 1.0)
+    np.add.at(deg, edges[:, 1], 1.0)
+    d = n + n_extra
+    ent = []
+    for i in range(n):
+        if deg[i] != 0.0:
+            ent.append((0, 1, i + 1, i + 1, deg[i] / 4.0))
+    for i, j in edges.tolist():
+        ent.append((0, 1, i + 1, j + 1, -0.25))
+    cost = 0.05 + 0.2 * rng.random(d)
+    for i in range(d):
+        ent.append((0, 2, i + 1, i + 1, -float(cost[i])))  # F0 = -c  =>  C = -F0 = +c
+    for i in range(n):
+        ent.append((i + 1, 1, i + 1, i + 1, 1.0))
+        ent.append((i + 1, 2, i + 1, i + 1, 1.0))
+    for j in range(n_extra):
+        r1 = int(rng.integers(0, n - 1))
+        ent.append((r1 + 1, 2, n + j + 1, n + j + 1, float(0.3 + 0.5 * rng.random())))
+        ent.append((r1 + 2, 2, n + j + 1, n + j + 1, float(0.2 + 0.4 * rng.random())))
+    ent.sort(key=lambda e: (e[0], e[1]))
+    return dict(m=n, blocks=[n, -d], b=np.ones(n), entries=ent)
+
+
 def coupled_blocks(nblk, n_k, m, seed, n_diag=2, n_off=4, r0=3, c_edges=None):
     """Block-diagonal SDP whose constraints COUPLE the blocks: every A_i has entries in every
     block (dense-cone branch per block; Gauss-Seidel != Jacobi)."""
@@ -243,6 +274,8 @@ NAMED = {
     "mix4": lambda: block_diag([maxcut(60, 90, 61), randsparse(70, 45, 62, c_edges=90, n_diag=2, n_off=3, r0=3),
                                 maxcut(66, 100, 63), matcomp(35, 33, 220, 3, 64)]),
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
+    # SDP cone + LP block (slacks and coupling columns): the LP path (closed-form column sweep)
+    "sdplp40": lambda: sdp_lp(40, 90, 12, 4001),
     # timing / log-level instances
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
     "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini

@@ -37,6 +37,7 @@ TRACE = {
     "densec40": (8, 3, ["--phase1Tol", "1e-2"]),
     "matcomp60": (8, 3, ["--phase1Tol", "1e-2"]),
     "mix4": (8, 3, ["--phase1Tol", "1e-2"]),
+    "sdplp40": (8, 3, ["--phase1Tol", "1e-2"]),
 }
 SOLVE = [
     ("maxcut100", ["--reoptLevel", "0"]),
@@ -50,6 +51,8 @@ SOLVE = [
     ("densec40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("matcomp60", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("mix4", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
+    ("sdplp40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
+    ("sdplp40", ["--reoptLevel", "0"]),
     ("maxcut800", ["--reoptLevel", "0"]),
     ("maxcut800", ["--reoptLevel", "0", "--phase1Tol", "1e-2"]),
 ]
@@ -73,7 +76,7 @@ def read_dump(path):
 
 
 def run_ref(args):
-    env = dict(os.environ, MKL_NUM_THREADS="1")
+    env = dict(os.environ, MKL_NUM_THREADS="1", LORADS_REF_ALLOW_LP="1")
     r = subprocess.run([os.path.join(HERE, "_ref", "ref_driver")] + args, env=env, capture_output=True, text=True,
                        timeout=1800)
     if r.returncode != 0:

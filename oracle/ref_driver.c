@@ -109,6 +109,8 @@ typedef struct {
     SDPConst sdpConst;
 } ctx_t;
 
+static lorads_solver *g_S; /* for the LP vectors that travel with the factor arrays in the dumps */
+
 /* setup = main.c:266-304 */
 static int setup(ctx_t *c, lorads_params *p) {
     memset(c, 0, sizeof *c);
@@ -118,7 +120,7 @@ static int setup(ctx_t *c, lorads_params *p) {
         fprintf(stderr, "read failed\n");
         return 1;
     }
-    if (c->nLpCols > 0) { fprintf(stderr, "LP block: out of scope\n"); return 1; }
+    if (c->nLpCols > 0 && !getenv("LORADS_REF_ALLOW_LP")) { fprintf(stderr, "LP block: out of scope\n"); return 1; }
     LORADS_INIT(c->S, lorads_solver, 1);
     LORADS_INIT(c->S->var, lorads_variable, 1);
     LORADSInitSolver(c->S, c->nConstrs, c->nBlks, c->BlkDims, c->nLpCols);
@@ -132,23 +134,27 @@ static int setup(ctx_t *c, lorads_params *p) {
     c->S->hisRecT = p->lbfgsListLength;
     LORADSInitADMMVars(c->S, c->S->var->rankElem, c->BlkDims, c->nBlks, c->nLpCols);
     initial_solver_state(p, c->S, &c->alm, &c->admm, &c->sdpConst);
+    g_S = c->S;
     return 0;
 }
 
 static void dump_problem_consts(ctx_t *c) {
     lorads_solver *S = c->S;
-    double *rk = malloc(sizeof(double) * c->nBlks), *nn = malloc(sizeof(double) * c->nBlks),
-           *ct = malloc(sizeof(double) * c->nBlks), *wt = malloc(sizeof(double) * c->nBlks);
+    /* the LP block (if any) is reported as one more "cone": rank 1, dimension nLpCols, branch flags -1 */
+    const int nall = (int)c->nBlks + (c->nLpCols > 0 ? 1 : 0);
+    double *rk = malloc(sizeof(double) * nall), *nn = malloc(sizeof(double) * nall),
+           *ct = malloc(sizeof(double) * nall), *wt = malloc(sizeof(double) * nall);
+    if (c->nLpCols > 0) { rk[nall - 1] = 1; nn[nall - 1] = c->nLpCols; ct[nall - 1] = -1; wt[nall - 1] = -1; }
     for (int k = 0; k < c->nBlks; ++k) {
         rk[k] = S->var->rankElem[k];
         nn[k] = c->BlkDims[k];
         ct[k] = (S->SDPCones[k]->type == LORADS_CONETYPE_SPARSE_SDP) ? 1.0 : 0.0;
         wt[k] = (S->SDPCones[k]->sdp_coeff_w_sum->dataType == SDP_COEFF_DENSE) ? 1.0 : 0.0;
     }
-    rec("rank", rk, c->nBlks);
-    rec("blkdims", nn, c->nBlks);
-    rec("cone_is_sparse", ct, c->nBlks);
-    rec("wsum_is_dense", wt, c->nBlks);
+    rec("rank", rk, nall);
+    rec("blkdims", nn, nall);
+    rec("cone_is_sparse", ct, nall);
+    rec("wsum_is_dense", wt, nall);
     rec1("m", c->nConstrs);
     rec1("rho0", c->alm.rho);
     rec1("cObjNrm1", S->cObjNrm1); rec1("cObjNrm2", S->cObjNrm2); rec1("cObjNrmInf", S->cObjNrmInf);
@@ -157,8 +163,18 @@ static void dump_problem_consts(ctx_t *c) {
     free(rk); free(nn); free(ct); free(wt);
 }
 
+static lorads_lp_dense *g_lp_of(lorads_solver *S, lorads_sdp_dense **M) { /* the LP vector that travels with M */
+    if (S->nLpCols <= 0) return NULL;
+    if (M == S->var->R) return S->var->rLp;
+    if (M == S->var->U) return S->var->uLp;
+    if (M == S->var->V) return S->var->vLp;
+    if (M == S->var->Grad) return S->var->gradLp;
+    return NULL;
+}
 static void dump_mats(const char *fmt, int it, lorads_sdp_dense **M, int nb) {
     for (int k = 0; k < nb; ++k) recf(fmt, it, k, M[k]->matElem, (int64_t)M[k]->nRows * M[k]->rank);
+    lorads_lp_dense *lp = g_S ? g_lp_of(g_S, M) : NULL;
+    if (lp) recf(fmt, it, nb, lp->matElem, (int64_t)lp->nCols); /* pseudo-cone index nb */
 }
 
 static void dump_final(ctx_t *c, int dump_state) {
@@ -304,9 +320,10 @@ static int mode_trace(ctx_t *c, lorads_params *p, int n_alm, int n_admm, double 
         double t0 = LUtilGetTimeStamp();
         LORADS_ALMOptimize(p, S, &c->alm, p->maxALMIter, t0);
         {
-            double rkw[64];
+            double rkw[65];
             for (int k = 0; k < nb && k < 64; ++k) rkw[k] = S->var->R[k]->rank;
-            rec("rank_warm", rkw, nb); /* phase 1 may have grown the rank (AUG_RANK) */
+            if (S->nLpCols > 0) rkw[nb < 64 ? nb : 64] = 1;
+            rec("rank_warm", rkw, nb + (S->nLpCols > 0 ? 1 : 0)); /* phase 1 may have grown the rank (AUG_RANK) */
         }
         dump_mats("R_warm_%d_%d", 0, S->var->R, nb);
         rec("lambda_warm", S->var->dualVar, m);

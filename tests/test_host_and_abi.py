@@ -69,10 +69,23 @@ def test_reader_conventions(tmp_path, oracle_lib):
         s.close()
 
 
-def test_reader_rejects_lp_block(tmp_path, oracle_lib):
-    path = _write(tmp_path, "1\n2\n2 -3\n1.0\n1 1 1 1 1.0\n")
-    with pytest.raises(RuntimeError):
-        host.Session.open(path, lib=oracle_lib)
+def test_reader_lp_block(tmp_path, oracle_lib):
+    """One diagonal (LP) block is accepted when it is the last block (io/lorads_file_io.c:120-124): it becomes a
+    cone image with is_lp semantics -- n = number of columns, rank 1, diagonal entries keyed by their row index.
+    Anywhere else, or of dimension 0, it is refused."""
+    path = _write(tmp_path, "2\n2\n2 -3\n1.0 2.0\n0 2 2 2 -0.5\n1 1 1 1 1.0\n1 2 1 1 1.0\n2 2 3 3 2.0\n2 2 1 1 0.5\n")
+    s = host.Session.open(path, lib=oracle_lib)
+    try:
+        s.set_params(verbose=0)
+        s.prepare()
+        assert (s.m, s.nblk) == (2, 2)
+        lp = s.block_info(1)
+        assert (lp["n"], lp["rank"], lp["nrow"], lp["na"], lp["nc"], lp["dense_mode"]) == (3, 1, 2, 3, 1, 0)
+    finally:
+        s.close()
+    for bad in ("1\n2\n-3 2\n1.0\n1 2 1 1 1.0\n", "1\n2\n2 0\n1.0\n1 1 1 1 1.0\n"):
+        with pytest.raises(RuntimeError):
+            host.Session.open(_write(tmp_path, bad), lib=oracle_lib)
 
 
 def test_rank_rule_and_branches(tmp_path, oracle_lib):
