@@ -41,6 +41,11 @@ typedef struct {
     const int32_t *c_row;
     const int32_t *c_col;
     const double *c_val;
+    /* 1: this is the LP block of the file (lorads_lp_cone, data/def_lorads_lp_conic.h; at most one, the last block):
+     * n = number of LP columns, rank 1, every entry diagonal ((i,i,a) = coefficient a of column i).  Phase 1 and the
+     * evaluations treat it as a diagonal cone; admm_update_var updates it column by column in closed form
+     * (LORADSUpdateSDPLPVar, lorads_alg_common.c:225-248). */
+    int32_t is_lp;
 } lorads_hip_block;
 
 typedef struct {

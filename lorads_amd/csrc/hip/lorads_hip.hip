@@ -822,6 +822,104 @@ __global__ void k_commit_csum(int m, const double *__restrict__ stage, double *_
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) csum[i] = stage[i];
 }
 
+// ---- LP block (one diagonal cone, rank 1, lorads_hip_block.is_lp).  In phase 1 and in every evaluation it runs
+// through the generic cone kernels.  The ADMM update is the reference's closed form, column by column in file order
+// (LORADSUpdateLPVarOne, lorads_admm.c:595-629; bookkeeping lorads_alg_common.c:236-246):
+//   m1_k = rho (csum[g_k] - cvLP_k - b[g_k]) - lambda[g_k],  w = c + sum_k m1_k a_k,
+//   u <- (-(w v - rho v) / rho) / (1 + ||a||^2 v^2),  cvLP_k <- a_k u v (csum follows),  then the same for v.
+// Columns that share no constraint row do not see each other, so the sweep is LEVEL-SCHEDULED: level(j) =
+// 1 + max level of the earlier columns sharing a row with j; columns of one level are updated in parallel, levels in
+// order -- exactly the sequential result.  Slack-type blocks (every column alone in its row) are one level.
+struct LpArgs {
+    int ncols, nlev;
+    const int *lvl_ptr, *lvl_cols, *ptr, *grow; // level -> columns; column -> entries; entry -> global constraint
+    const double *a, *nrm2sq, *cobj;
+    double *cv, *U, *V, *csum;
+    const double *b, *lambda;
+    double rho;
+};
+__device__ __forceinline__ double lp_new_value(const LpArgs &A, int col, double fixed) {
+    double w = A.cobj[col];
+    for (int t = A.ptr[col]; t < A.ptr[col + 1]; ++t) {
+        const int g = A.grow[t];
+        double m1 = A.b[g];
+        m1 *= -1.0;
+        m1 += A.csum[g];
+        m1 += -1.0 * A.cv[t];
+        m1 *= A.rho;
+        m1 += -1.0 * A.lambda[g];
+        w += m1 * A.a[t];
+    }
+    double M2 = w * fixed;
+    M2 = M2 - A.rho * fixed;
+    const double blin = -1.0 * M2 / A.rho;
+    return blin / (1 + A.nrm2sq[col] * fixed * fixed);
+}
+__device__ __forceinline__ void lp_refresh(const LpArgs &A, int col, double uv) {
+    for (int t = A.ptr[col]; t < A.ptr[col + 1]; ++t) {
+        const int g = A.grow[t];
+        double cs = A.csum[g] + -1.0 * A.cv[t];
+        const double nv = A.a[t] * uv;
+        A.cv[t] = nv;
+        A.csum[g] = cs + nv;
+    }
+}
+__device__ __forceinline__ void lp_column(const LpArgs &A, int col) {
+    const double u = lp_new_value(A, col, A.V[col]);
+    A.U[col] = u;
+    lp_refresh(A, col, u * A.V[col]);
+    const double v = lp_new_value(A, col, u);
+    A.V[col] = v;
+    lp_refresh(A, col, u * v);
+}
+// one workgroup walks the levels; done words of the block's two stages are set at the end
+__global__ __launch_bounds__(TPB) void k_lp_sweep(LpArgs A, CGState *st, Guard g) {
+    if (blocked(g)) return;
+    for (int lev = 0; lev < A.nlev; ++lev) {
+        for (int i = A.lvl_ptr[lev] + threadIdx.x; i < A.lvl_ptr[lev + 1]; i += TPB) lp_column(A, A.lvl_cols[i]);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st[0].iter = 0; st[0].nan = 0; st[0].pad = 1; st[0].done = 1;
+        st[1].iter = 0; st[1].nan = 0; st[1].pad = 1; st[1].done = 1;
+    }
+}
+// single level: every column independent, many workgroups; the done words are set by k_lp_done afterwards
+__global__ __launch_bounds__(TPB) void k_lp_sweep_flat(LpArgs A, Guard g) {
+    if (blocked(g)) return;
+    const int col = blockIdx.x * TPB + threadIdx.x;
+    if (col < A.ncols) lp_column(A, col);
+}
+__global__ void k_lp_done(CGState *st, Guard g) {
+    if (blocked(g)) return;
+    st[0].iter = 0; st[0].nan = 0; st[0].pad = 1; st[0].done = 1;
+    st[1].iter = 0; st[1].nan = 0; st[1].pad = 1; st[1].done = 1;
+}
+// constrValLP: cv_t = a_t x_col y_col for every stored entry (lp_cone_AUV, data/lorads_lp_conic.c:172-175)
+__global__ void k_lp_cv(int ncols, const int *__restrict__ ptr, const double *__restrict__ a, const double *__restrict__ X,
+                        const double *__restrict__ Y, double *__restrict__ cv, Guard g) {
+    if (blocked(g)) return;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const double uv = X[col] * Y[col];
+    for (int t = ptr[col]; t < ptr[col + 1]; ++t) cv[t] = a[t] * uv;
+}
+// sum over the columns of |min(c - sum_k lambda a, 0)| (data/lorads_solver.c:1015-1023), one workgroup
+__global__ __launch_bounds__(TPB) void k_lp_dual(int ncols, const int *__restrict__ ptr, const int *__restrict__ grow,
+                                                 const double *__restrict__ a, const double *__restrict__ cobj,
+                                                 const double *__restrict__ lambda, double *out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int col = threadIdx.x; col < ncols; col += TPB) {
+        double w = cobj[col];
+        for (int t = ptr[col]; t < ptr[col + 1]; ++t) w += -lambda[grow[t]] * a[t];
+        acc += fabs(w < 0.0 ? w : 0.0);
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) *out = acc;
+}
+
 // ---- small vector kernels
 __global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out, Guard g) {
     if (blocked(g)) return;
@@ -1213,6 +1311,10 @@ struct Block {
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
+    bool is_lp = false;       // the LP block: generic diagonal cone everywhere except the ADMM update (k_lp_sweep)
+    int lp_nlev = 0;
+    int *lp_lvl_ptr = nullptr, *lp_lvl_cols = nullptr, *lp_ptr = nullptr, *lp_grow = nullptr;
+    double *lp_a = nullptr, *lp_nrm2sq = nullptr, *lp_cobj = nullptr, *lp_cv = nullptr;
     bool entry_only = false;  // every A_i is a single (off-)diagonal entry (matrix completion): k_op_entry
     double *gentry = nullptr; // sum of a_i^2 per A-pattern entry
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
@@ -1424,7 +1526,7 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
     build_transpose((int)uniqA.size(), hb.nrow, hb.a_ptr, a_e, hb.a_val, hpA);
     if (upload_pattern(B.pa, hpA, nullptr)) return 1;
     // dense objective (the reference's rule for a dense coefficient, lorads_sdp_data.c:818-821)
-    B.dense_c = (double)B.nc > 0.1 * (double)((int64_t)B.n * (B.n + 1) / 2) && B.r <= 128;
+    B.dense_c = !hb.is_lp && (double)B.nc > 0.1 * (double)((int64_t)B.n * (B.n + 1) / 2) && B.r <= 128;
     if (B.dense_c) {
         B.npad = (B.n + 63) / 64 * 64;
         // split K over workgroups until the grid has >= 512 of them (K range a multiple of 32)
@@ -1479,6 +1581,52 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
         B.entry_only = true;
     }
     if (!diag && build_gram(B, hb, a_e, B.pa.ne)) return 1;
+    if (hb.is_lp) { // column-wise image + level schedule of the LP block
+        for (int t = 0; t < B.na; ++t)
+            if (hb.a_row[t] != hb.a_col[t]) return fail_msg("LP block: off-diagonal entry");
+        for (int t = 0; t < B.nc; ++t)
+            if (hb.c_row[t] != hb.c_col[t]) return fail_msg("LP block: off-diagonal objective entry");
+        const int n = B.n;
+        std::vector<int> ptr(n + 1, 0), grow(B.na), fill(n, 0);
+        std::vector<double> av(B.na), nrm(n, 0.0), cobj(n, 0.0);
+        for (int t = 0; t < B.na; ++t) ptr[hb.a_row[t] + 1]++;
+        for (int j = 0; j < n; ++j) ptr[j + 1] += ptr[j];
+        for (int i = 0; i < hb.nrow; ++i)
+            for (int t = hb.a_ptr[i]; t < hb.a_ptr[i + 1]; ++t) {
+                const int col = hb.a_row[t], w = ptr[col] + fill[col]++;
+                grow[w] = hb.row_idx[i];
+                av[w] = hb.a_val[t];
+            }
+        for (int j = 0; j < n; ++j) {
+            double nn = 0.0;
+            for (int t = ptr[j]; t < ptr[j + 1]; ++t) nn += av[t] * av[t];
+            const double nr = std::sqrt(nn); // nrm2, then squared (data/lorads_lp_conic.c:112-113)
+            nrm[j] = nr * nr;
+        }
+        for (int t = 0; t < B.nc; ++t) cobj[hb.c_row[t]] += hb.c_val[t];
+        // level(j) = 1 + max level of the earlier columns that share a constraint row with j
+        std::vector<int> row_lvl((size_t)std::max(c->m, 1), 0), lvl(n, 0);
+        int nlev = 0;
+        for (int j = 0; j < n; ++j) {
+            int l = 0;
+            for (int t = ptr[j]; t < ptr[j + 1]; ++t) l = std::max(l, row_lvl[grow[t]]);
+            lvl[j] = l; // 0-based level
+            for (int t = ptr[j]; t < ptr[j + 1]; ++t) row_lvl[grow[t]] = l + 1;
+            nlev = std::max(nlev, l + 1);
+        }
+        std::vector<int> lptr(nlev + 1, 0), lcols(n);
+        for (int j = 0; j < n; ++j) lptr[lvl[j] + 1]++;
+        for (int l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+        std::vector<int> lf(lptr.begin(), lptr.end() - 1);
+        for (int j = 0; j < n; ++j) lcols[lf[lvl[j]]++] = j;
+        if (upload(&B.lp_ptr, ptr) || upload(&B.lp_grow, grow) || upload(&B.lp_a, av) || upload(&B.lp_nrm2sq, nrm) ||
+            upload(&B.lp_cobj, cobj) || upload(&B.lp_lvl_ptr, lptr) || upload(&B.lp_lvl_cols, lcols) ||
+            dalloc(&B.lp_cv, (size_t)B.na))
+            return 1;
+        HC(hipMemset(B.lp_cv, 0, sizeof(double) * (size_t)std::max(B.na, 1)));
+        B.is_lp = true;
+        B.lp_nlev = nlev;
+    }
     return 0;
 }
 
@@ -1530,6 +1678,8 @@ Block *solo(lorads_hip_ctx *c) {
 int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
     c->merged_ok = c->has_merged = false;
     if (c->nb < 2 || getenv("LORADS_NO_MERGE")) return 0;
+    for (int k = 0; k < c->nb; ++k)
+        if (prob->blocks[k].is_lp) return 0; // the LP block has its own update; no merged view with one present
     std::vector<char> seen((size_t)std::max(c->m, 1), 0);
     size_t ntot = 0, nrow = 0, na = 0, nc = 0;
     for (int k = 0; k < c->nb; ++k) {
@@ -1565,7 +1715,7 @@ int build_merged(lorads_hip_ctx *c, const lorads_hip_problem *prob) {
         roff += pad_rows(hb.n);
     }
     c->seg_row0_h.push_back(roff);
-    lorads_hip_block mb;
+    lorads_hip_block mb{};
     mb.n = (int)ntot; mb.rank = prob->blocks[0].rank; mb.nrow = (int)nrow; mb.row_idx = row_idx.data(); mb.a_ptr = a_ptr.data();
     mb.a_row = a_row.data(); mb.a_col = a_col.data(); mb.a_val = a_val.data(); mb.c_nnz = (int)nc; mb.c_row = c_row.data();
     mb.c_col = c_col.data(); mb.c_val = c_val.data();
@@ -1908,6 +2058,26 @@ Solve make_solve(lorads_hip_ctx *c, int k, int half, const int *need) {
     return s;
 }
 
+// the LP block's ADMM update (see k_lp_sweep); st = the block's two stage states
+void enqueue_lp_sweep(lorads_hip_ctx *c, Block &B, double rho, CGState *st, Guard g) {
+    LpArgs A;
+    A.ncols = B.n; A.nlev = B.lp_nlev; A.lvl_ptr = B.lp_lvl_ptr; A.lvl_cols = B.lp_lvl_cols; A.ptr = B.lp_ptr; A.grow = B.lp_grow;
+    A.a = B.lp_a; A.nrm2sq = B.lp_nrm2sq; A.cobj = B.lp_cobj; A.cv = B.lp_cv; A.U = c->U + B.off; A.V = c->V + B.off;
+    A.csum = c->csum; A.b = c->b; A.lambda = c->lambda; A.rho = rho;
+    B.t_uv_valid = false;
+    if (B.lp_nlev <= 1) {
+        LAUNCH(k_lp_sweep_flat, nblocks_for((size_t)B.n, TPB), A, g);
+        hipLaunchKernelGGL(k_lp_done, dim3(1), dim3(1), 0, c->stream, st, g);
+    } else {
+        LAUNCH(k_lp_sweep, 1, A, st, g);
+    }
+}
+// constrValLP of the LP block from the pair (X, Y)
+void lp_col_values(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, Guard g) {
+    if (!B.is_lp || B.n == 0) return;
+    LAUNCH(k_lp_cv, nblocks_for((size_t)B.n, TPB), B.n, B.lp_ptr, B.lp_a, X + B.off, Y + B.off, B.lp_cv, g);
+}
+
 // LORADSUpdateSDPVar (lorads_alg_common.c:187-215) for all cones of this context, enqueued speculatively
 // from stage `first` (stage = 2*cone + half); `resume_iter` >= 0 resumes that stage's CG after that many
 // completed iterations
@@ -1917,6 +2087,10 @@ void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, do
         const int *need = stg == 0 ? nullptr : &c->st[stg - 1].done;
         Solve s = make_solve(c, k, half, need);
         Block &B = *s.B;
+        if (B.is_lp) { // both halves of every column in one go at the block's first stage; never a speculation miss
+            if (half == 0) enqueue_lp_sweep(c, B, rho, c->st + stg, Guard{nullptr, need});
+            continue;
+        }
         if (stg == first && resume_iter >= 0) {
             const int more = std::max(2, std::min(resume_iter, 16));
             if (resume_iter > 0) solve_iter_tail(c, s, resume_iter - 1, tol, maxit);
@@ -1968,6 +2142,7 @@ int enqueue_eval(lorads_hip_ctx *c, int pair, const int *need, bool with_obj = t
         } else {
             constr_val(c, B, c->R + B.off, c->R + B.off, 1.0, B.cv, (single && !c->ar) ? CV_SET : CV_ADD, dst, g);
         }
+        lp_col_values(c, B, c->R, c->R, g); // primalInfeasibilityLP re-initialises constrValLP too (:260-262)
         if (!with_obj) continue; // DIMACS refresh alone (lorads_alg_common.c:250-290) does not touch the objective
         const int go = obj_partials(c, B, c->R + B.off, c->R + B.off, part_slot(c, 4), g);
         if (fold_obj) { nobj = go; continue; }
@@ -2226,7 +2401,8 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.g_ptr); hipFree(B.g_col);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
+        hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
     free_factors(c);
@@ -2270,7 +2446,10 @@ int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
     c->ls_np = 0;
     const double *X = pair == LORADS_HIP_PAIR_RR ? c->R : c->U, *Y = pair == LORADS_HIP_PAIR_RR ? c->R : c->V;
     LAUNCH(k_zero, grid1d((size_t)c->m + 2), (size_t)c->m + 2, c->csum, NOGUARD);
-    for (auto &B : c->blk) constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, CV_ADD, c->csum, NOGUARD);
+    for (auto &B : c->blk) {
+        constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, CV_ADD, c->csum, NOGUARD);
+        lp_col_values(c, B, X, Y, NOGUARD);
+    }
     return allreduce_dev(c, c->csum, c->m);
 }
 
@@ -2595,6 +2774,7 @@ int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
         if (B.dense_c) LAUNCH(k_scale, grid1d((size_t)B.npad * B.npad), (size_t)B.npad * B.npad, s, B.Cfull);
+        if (B.is_lp && B.n) LAUNCH(k_scale, grid1d((size_t)B.n), (size_t)B.n, s, B.lp_cobj);
     }
     if (c->m) LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, s, c->lambda);
     return 0;

@@ -137,6 +137,7 @@ int lrd_hip_backend_create(const lrd_problem *p, int lbfgs_len, const char *libp
         hb[k].n = b->n; hb[k].rank = b->rank; hb[k].nrow = b->nrow; hb[k].row_idx = b->row_idx; hb[k].a_ptr = b->a_ptr;
         hb[k].a_row = b->a_row; hb[k].a_col = b->a_col; hb[k].a_val = b->a_val; hb[k].c_nnz = b->c_nnz;
         hb[k].c_row = b->c_row; hb[k].c_col = b->c_col; hb[k].c_val = b->c_val;
+        hb[k].is_lp = b->is_lp;
     }
     lorads_hip_problem hp;
     memset(&hp, 0, sizeof hp);

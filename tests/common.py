@@ -200,6 +200,7 @@ def slack_matrices(prob, lam):
     import scipy.sparse as sp
     out = []
     for k, n in enumerate(prob["blocks"]):
+        n = abs(n)  # a negative dimension marks the LP block (diagonal)
         rows, cols, vals = [], [], []
         for mat, blk, i, j, v in prob["entries"]:
             if blk - 1 != k:
@@ -223,3 +224,19 @@ def c_norm1(prob):
     for (blk, i, j), v in acc.items():
         t += abs(v) * (1 if i == j else 2)
     return t
+
+
+def exact_dual_infeasibility(prob, lam):
+    """(sum, per-block lambda_min) of what calculate_dual_infeasibility_solver accumulates (data/lorads_solver.c:1015-1033):
+    |min(lambda_min(S_k), 0)| per SDP cone, and for the LP block every column on its own: sum_i |min(S_ii, 0)|."""
+    tot, mins = 0.0, []
+    for S, n in zip(slack_matrices(prob, lam), prob["blocks"]):
+        if n < 0:
+            d = S.diagonal()
+            tot += float(np.abs(np.minimum(d, 0.0)).sum())
+            mins.append(0.0)
+        else:
+            e = float(np.linalg.eigvalsh(S.toarray())[0])
+            tot += abs(min(e, 0.0))
+            mins.append(e)
+    return tot, mins

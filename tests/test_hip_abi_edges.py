@@ -14,7 +14,8 @@ _ip, _dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
 
 class Block(C.Structure):
     _fields_ = [("n", C.c_int32), ("rank", C.c_int32), ("nrow", C.c_int32), ("row_idx", _ip), ("a_ptr", _ip), ("a_row", _ip),
-                ("a_col", _ip), ("a_val", _dp), ("c_nnz", C.c_int32), ("c_row", _ip), ("c_col", _ip), ("c_val", _dp)]
+                ("a_col", _ip), ("a_val", _dp), ("c_nnz", C.c_int32), ("c_row", _ip), ("c_col", _ip), ("c_val", _dp),
+                ("is_lp", C.c_int32)]
 
 
 class Problem(C.Structure):
