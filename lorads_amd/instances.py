@@ -276,6 +276,7 @@ NAMED = {
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
     # SDP cone + LP block (slacks and coupling columns): the LP path (closed-form column sweep)
     "sdplp40": lambda: sdp_lp(40, 90, 12, 4001),
+    "sdpslack30": lambda: sdp_lp(30, 60, 0, 4002),         # slacks only: every LP column alone in its row (one level)
     # timing / log-level instances
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
     "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini
