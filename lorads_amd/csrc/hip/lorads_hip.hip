@@ -2081,7 +2081,7 @@ void lp_col_values(lorads_hip_ctx *c, Block &B, const double *X, const double *Y
 // LORADSUpdateSDPVar (lorads_alg_common.c:187-215) for all cones of this context, enqueued speculatively
 // from stage `first` (stage = 2*cone + half); `resume_iter` >= 0 resumes that stage's CG after that many
 // completed iterations
-void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, double tol, int maxit) {
+void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, double tol, int maxit, bool eval_follows) {
     for (int stg = first; stg < 2 * c->nb; ++stg) {
         const int k = stg / 2, half = stg % 2;
         const int *need = stg == 0 ? nullptr : &c->st[stg - 1].done;
@@ -2101,7 +2101,16 @@ void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, do
             solve_front(c, s, rho, tol, fresh0 ? c->st + 1 : nullptr, fresh0 ? 2 * c->nb - 1 : 0);
             solve_iters(c, s, 0, std::min(B.spec[half], maxit), tol, maxit);
         }
-        refresh_after_solve(c, B, &s.st->done);
+        if (eval_follows && stg == 2 * c->nb - 1) {
+            // the evaluation that follows overwrites constrVal / constrValSum with A(R R^T) (Q1): after the very last
+            // solve only the pair dots are kept (the next sweep's first residual re-uses them)
+            if (!B.diag_only && !B.entry_only) { // (those operators never read the pair dots)
+                pairdots(c, B.pa, c->U + B.off, c->V + B.off, B.r, B.T, Guard{nullptr, &s.st->done});
+                B.t_uv_valid = true;
+            }
+        } else {
+            refresh_after_solve(c, B, &s.st->done);
+        }
     }
 }
 
@@ -2241,7 +2250,8 @@ void batched_iters(lorads_hip_ctx *c, int half, int k0, int k1, double tol, int 
     }
 }
 // returns the number of lockstep iterations enqueued so far for `phase` (for a later resume)
-void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, double tol, int maxit, int launched[2]) {
+void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, double tol, int maxit, int launched[2],
+                     bool eval_follows) {
     Block &M = c->merged;
     for (int half = phase; half < 2; ++half) {
         const double *Vfix = half == 0 ? c->V : c->U;
@@ -2265,14 +2275,21 @@ void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, doubl
             launched[half] = k1;
         }
         // constrVal <- A(sym(U V^T)), constrValSum += new - old for every cone at once
-        constr_val(c, M, c->U, c->V, 1.0, M.cv, CV_DELTA, c->csum, Guard{nullptr, &c->phase_done[half]});
+        if (eval_follows && half == 1) { // dead before the evaluation (see enqueue_sweep): keep the pair dots only
+            if (!M.diag_only && !M.entry_only) {
+                pairdots(c, M.pa, c->U, c->V, M.r, M.T, Guard{nullptr, &c->phase_done[half]});
+                M.t_uv_valid = true;
+            }
+        } else {
+            constr_val(c, M, c->U, c->V, 1.0, M.cv, CV_DELTA, c->csum, Guard{nullptr, &c->phase_done[half]});
+        }
     }
 }
 int run_sweep_batched(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_eval) {
     int phase = 0, resume = -1, launched[2] = {0, 0};
     bool first_pass = true, any_missed = false;
     for (;;) {
-        enqueue_batched(c, phase, resume, rho, tol, maxit, launched);
+        enqueue_batched(c, phase, resume, rho, tol, maxit, launched, with_eval);
         // the evaluation rides along speculatively; with sharded cones only in the first pass (see run_sweep)
         const bool eval_now = with_eval && (!c->ar || first_pass);
         if (eval_now && enqueue_eval(c, LORADS_HIP_PAIR_UV, &c->phase_done[1])) return 1;
@@ -2315,7 +2332,7 @@ int run_sweep(lorads_hip_ctx *c, double rho, double tol, int maxit, bool with_ev
     // blocked (and block its successors) instead of seeing last iteration's done word
     if (2 * c->nb - 1 > TPB) HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * (size_t)(2 * c->nb), c->stream));
     for (;;) {
-        enqueue_sweep(c, first, resume, rho, tol, maxit);
+        enqueue_sweep(c, first, resume, rho, tol, maxit, with_eval);
         // With sharded cones the evaluation contains the all-reduce, a collective every rank must enter the same
         // number of times, whatever its own speculation did.  Every rank enters it once in the first pass, and the
         // reduced vector carries one extra word: how many ranks missed.  If any did, every rank finishes its sweep

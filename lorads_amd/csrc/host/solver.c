@@ -268,7 +268,8 @@ restart:
             if (cert_val <= cert_tol) break;
             /* fused path: the table offers the inner iteration as two calls with one host round trip each and
              * pre-computes the next direction while the host looks at this one's results */
-            const int fused = be->alm_step && be->alm_front && s->use_fused_step && !s->allreduce;
+            /* (with sharded cones too: every collective inside is entered by all ranks alike) */
+            const int fused = be->alm_step && be->alm_front && s->use_fused_step;
             int have_front = 0;
             double front[6] = {0, 0, 0, 0, 0, 0};
             while (cert_val - cert_tol > par->endALMSubTol) {
