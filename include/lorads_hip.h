@@ -157,7 +157,7 @@ int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes_matvec, double *bytes_cg_iter);
 /* which kernels apply the CG operator of block blk: 0 = k_pairdots + k_sgram + k_spmm (Gram of the A_i),
  * 1 = k_pairdots + k_cv + k_sval + k_spmm, 2 = k_op_diag (every A_i one diagonal entry), 3 = k_op_entry (every A_i
- * one entry) */
+ * one entry), 4 = k_cw + k_spmm<CW> (constraint values straight from the factors, slot coefficients a w_i) */
 int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
 int lorads_hip_sync(lorads_hip_ctx *ctx);
 

@@ -46,6 +46,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "lorads_hip.h"
@@ -195,6 +196,48 @@ __global__ __launch_bounds__(TPB) void k_pairdots(int ne, const int *__restrict_
     double s = pair_dot<LG, V2, NS>(X, Y, p, q, r, lane);
     s = group_sum<LG>(s);
     if (live && act && lane == 0) T[e] = s;
+}
+
+// Constraint values straight from the factors: w_i = sum_{entries e of A_i} a_e pairdot_e(X, Y), ONE WAVEFRONT PER
+// CONSTRAINT (64 / LG entries in flight, LG lanes each), then the same bookkeeping as k_cv -- the pair-dot array T is
+// never written.  w_out (may be null) additionally keeps the plain values (the operator's constraint weights).
+template <int LG, bool V2, int NS>
+__global__ __launch_bounds__(TPB) void k_cw(int nrow, const int *__restrict__ a_ptr, const int *__restrict__ a_p,
+                                            const double *__restrict__ a_val, const int *__restrict__ a_q,
+                                            const double *__restrict__ X,
+                                            const double *__restrict__ Y, int r, double scale, double *__restrict__ w_out,
+                                            double *__restrict__ cv, int mode, const int *__restrict__ row_idx,
+                                            double *__restrict__ vec, Guard g) {
+    const bool live = !blocked(g);
+    constexpr int GR = 64 / LG; // entry groups per wavefront
+    const int i = (blockIdx.x * TPB + threadIdx.x) >> 6, lane64 = threadIdx.x & 63;
+    const int grp = lane64 / LG, lane = lane64 % LG;
+    const bool act = i < nrow;
+    const int ic = act ? i : 0;
+    const int t0 = a_ptr[ic], t1 = act ? a_ptr[ic + 1] : t0;
+    // two entries per group and trip: the (row, col, a) of both are fetched before the first row gather (rows and
+    // columns are stored per constraint entry -- no detour through the pattern entry)
+    double acc = 0.0;
+    for (int t = t0 + grp; t < t1; t += 2 * GR) {
+        const int tb = t + GR < t1 ? t + GR : t;
+        const int p0 = a_p[t], q0 = a_q[t], p1 = a_p[tb], q1 = a_q[tb];
+        const double c0 = a_val[t], c1 = t + GR < t1 ? a_val[tb] : 0.0;
+        const double d0 = pair_dot<LG, V2, NS>(X, Y, p0, q0, r, lane);
+        const double d1 = pair_dot<LG, V2, NS>(X, Y, p1, q1, r, lane);
+        acc += c0 * d0;
+        acc += c1 * d1;
+    }
+    const double s = wave_sum(acc);
+    if (live && act && lane64 == 0) {
+        if (w_out) w_out[i] = s;
+        if (vec) {
+            const int gi = row_idx[i];
+            if (mode == CV_SET) vec[gi] = s * scale;
+            else if (mode == CV_ADD) vec[gi] += s * scale;
+            else vec[gi] += s - cv[i];
+        }
+        if (cv) cv[i] = s;
+    }
 }
 
 // Both pair dots of the line search from one visit of the four rows (ALMCalq12p12, lorads_alm.c:540-560):
@@ -354,12 +397,15 @@ __global__ __launch_bounds__(TPB) void k_sgram(int ne, const int *__restrict__ g
 }
 
 // Y_p = epilogue( sum over the neighbours (q,e) of row p of S_e X_q ), LG lanes per row, + fused reduction.
-template <int LG, bool V2, int NS>
+// CW = true: the slot list is per (neighbour, constraint): adj_e holds the compact constraint index, S the constraint
+// weights w and adj_a the coefficient a, so that the slot coefficient a * w[con] is formed without an S array.
+template <int LG, bool V2, int NS, bool CW = false>
 __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj_ptr, const int *__restrict__ adj_col,
                                               const int *__restrict__ adj_e, const double *__restrict__ S,
                                               const double *__restrict__ X, int r, int mode, const double *__restrict__ xin,
                                               const double *__restrict__ rhs, double rho, double *__restrict__ out,
-                                              double *__restrict__ part, Guard g, const double *__restrict__ dense_add) {
+                                              double *__restrict__ part, Guard g, const double *__restrict__ dense_add,
+                                              const double *__restrict__ adj_a = nullptr) {
     __shared__ double sh[4];
     const bool live = !blocked(g);
     constexpr int W = V2 ? 2 : 1;
@@ -387,16 +433,18 @@ __global__ __launch_bounds__(TPB) void k_spmm(int n, const int *__restrict__ adj
     // before the first use (out-of-range slots repeat the last neighbour with coefficient 0)
     for (int t = t0; t < t1; t += 4) {
         int q[4], e[4];
+        double aa[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tt = t + u < t1 ? t + u : t1 - 1;
             q[u] = adj_col[tt];
             e[u] = adj_e[tt];
+            aa[u] = CW ? adj_a[tt] : 1.0;
         }
         double sc[4], v[4][NS][W];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            sc[u] = S[e[u]];
+            sc[u] = CW ? aa[u] * S[e[u]] : S[e[u]];
             Slice<LG, V2, NS>::load(X + (size_t)q[u] * r, r, lane, v[u]);
         }
 #pragma unroll
@@ -920,6 +968,20 @@ __global__ __launch_bounds__(TPB) void k_lp_dual(int ncols, const int *__restric
     if (threadIdx.x == 0) *out = acc;
 }
 
+// Result hand-over without hipStreamSynchronize: one workgroup copies `nwords` 8-byte words of the control block into
+// host-mapped pinned memory, fences at system scope and then publishes a sequence number the host spins on.  Cuts the
+// per-iteration wake-up latency of an interrupt-driven stream synchronisation (and the separate copy kernel).
+__global__ __launch_bounds__(TPB) void k_publish(const unsigned long long *__restrict__ src, int nwords, unsigned long long *dst,
+                                                 unsigned long long *flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < nwords; i += TPB) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+        __threadfence_system();
+    }
+}
+
 // ---- small vector kernels
 __global__ void k_average(size_t len, const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ out, Guard g) {
     if (blocked(g)) return;
@@ -1311,6 +1373,11 @@ struct Block {
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
+    bool use_cw = false;      // operator = k_cw (constraint values from the factors) + k_spmm<CW> (slot coefficient a w_i)
+    int *cadj_ptr = nullptr, *cadj_col = nullptr, *cadj_con = nullptr; // row -> (neighbour, compact constraint, a)
+    int *ca_row = nullptr, *ca_col = nullptr; // (row, col) of every constraint entry, in constraint-CSR order
+    double *cadj_a = nullptr;
+    double *w_uv = nullptr, *w_op = nullptr; // A(sym(U V^T)) kept for re-use (valid <=> t_uv_valid); operator scratch
     bool is_lp = false;       // the LP block: generic diagonal cone everywhere except the ADMM update (k_lp_sweep)
     int lp_nlev = 0;
     int *lp_lvl_ptr = nullptr, *lp_lvl_cols = nullptr, *lp_ptr = nullptr, *lp_grow = nullptr;
@@ -1351,6 +1418,9 @@ struct lorads_hip_ctx {
     double *part = nullptr;   // NSLOT x MAXPART partial sums
     int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
     char *ctrl = nullptr, *h_ctrl = nullptr; // [64 scalars | CG states] device + pinned mirror: ONE readback copy
+    char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
+    unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
+    bool use_publish = true;
     double *scal = nullptr;   // 64 device scalars
     CGState *st = nullptr;    // one per (cone, half)
     CGState *h_st = nullptr;  // pinned mirror
@@ -1581,6 +1651,45 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
         B.entry_only = true;
     }
     if (!diag && build_gram(B, hb, a_e, B.pa.ne)) return 1;
+    // Constraint-wise operator (k_cw + k_spmm<CW>): worthwhile when there are enough constraints to fill the device
+    // with one wavefront each and none of them is so large that a single wavefront would crawl through it.
+    {
+        int maxsz = 0;
+        for (int i = 0; i < hb.nrow; ++i) maxsz = std::max(maxsz, hb.a_ptr[i + 1] - hb.a_ptr[i]);
+        const char *force = getenv("LORADS_OP_CW"); // "1" force on, "0" force off (tests / comparisons)
+        bool want = !diag && !B.entry_only && hb.nrow >= 256 && maxsz <= 512;
+        if (force && !diag && !B.entry_only && hb.nrow > 0) want = force[0] == '1';
+        if (want) {
+            std::vector<int> deg(B.n + 1, 0);
+            for (int t = 0; t < B.na; ++t) {
+                deg[hb.a_row[t] + 1]++;
+                if (hb.a_row[t] != hb.a_col[t]) deg[hb.a_col[t] + 1]++;
+            }
+            std::vector<int> ptr(B.n + 1, 0);
+            for (int i = 0; i < B.n; ++i) ptr[i + 1] = ptr[i] + deg[i + 1];
+            std::vector<int> col(ptr[B.n]), con(ptr[B.n]), fill(ptr.begin(), ptr.end() - 1);
+            std::vector<double> av(ptr[B.n]);
+            for (int i = 0; i < hb.nrow; ++i)
+                for (int t = hb.a_ptr[i]; t < hb.a_ptr[i + 1]; ++t) {
+                    const int p = hb.a_row[t], q = hb.a_col[t];
+                    col[fill[p]] = q; con[fill[p]] = i; av[fill[p]] = hb.a_val[t]; fill[p]++;
+                    if (p != q) { col[fill[q]] = p; con[fill[q]] = i; av[fill[q]] = hb.a_val[t]; fill[q]++; }
+                }
+            for (int i = 0; i < B.n; ++i) { // neighbours in ascending (row, constraint) order: fixed summation order
+                const int s0 = ptr[i], s1 = ptr[i + 1];
+                std::vector<std::tuple<int, int, double>> tmp(s1 - s0);
+                for (int k = s0; k < s1; ++k) tmp[k - s0] = std::make_tuple(col[k], con[k], av[k]);
+                std::sort(tmp.begin(), tmp.end());
+                for (int k = s0; k < s1; ++k) { col[k] = std::get<0>(tmp[k - s0]); con[k] = std::get<1>(tmp[k - s0]); av[k] = std::get<2>(tmp[k - s0]); }
+            }
+            std::vector<int> car(hb.a_row, hb.a_row + B.na), cac(hb.a_col, hb.a_col + B.na);
+            if (upload(&B.ca_row, car) || upload(&B.ca_col, cac) ||
+                upload(&B.cadj_ptr, ptr) || upload(&B.cadj_col, col) || upload(&B.cadj_con, con) || upload(&B.cadj_a, av) ||
+                dalloc(&B.w_uv, (size_t)B.nrow) || dalloc(&B.w_op, (size_t)B.nrow))
+                return 1;
+            B.use_cw = true;
+        }
+    }
     if (hb.is_lp) { // column-wise image + level schedule of the LP block
         for (int t = 0; t < B.na; ++t)
             if (hb.a_row[t] != hb.a_col[t]) return fail_msg("LP block: off-diagonal entry");
@@ -1844,6 +1953,25 @@ int spmm(lorads_hip_ctx *c, const Block &B, const Pattern &P, const double *X, i
                               out, part, g, dense_add));
     return grid;
 }
+// epilogue(x + sum over (neighbour, constraint) slots of a w_i V_q): the operator's SpMM with the coefficients formed
+// from the constraint weights w
+int spmm_cw(lorads_hip_ctx *c, const Block &B, const double *w, const double *X, int mode, const double *xin, const double *rhs,
+            double *out, double *part, Guard g) {
+    const Shape sh = shape_for(B.r);
+    const int grid = nblocks_for((size_t)B.n, TPB / sh.lg);
+    SHAPE_DISPATCH(sh, LAUNCH((k_spmm<LG_, V2_, NS_, true>), grid, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, w, X, B.r, mode, xin, rhs,
+                              0.0, out, part, g, (const double *)nullptr, B.cadj_a));
+    return grid;
+}
+// w_i = A_i(sym(X Y^T)) for every constraint of the cone + k_cv's bookkeeping, without the pair-dot array
+void cw(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, double scale, double *w_out, double *cv, int mode,
+        double *vec, Guard g) {
+    if (B.nrow == 0) return;
+    const Shape sh = shape_for(B.r);
+    const int grid = nblocks_for((size_t)B.nrow, TPB / 64);
+    SHAPE_DISPATCH(sh, LAUNCH((k_cw<LG_, V2_, NS_>), grid, B.nrow, B.a_ptr, B.ca_row, B.a_val, B.ca_col, X, Y, B.r, scale,
+                              w_out, cv, mode, B.row_idx, vec, g));
+}
 // W = C X on the matrix cores (dense objective only)
 int dense_cx(lorads_hip_ctx *c, const Block &B, const double *X, double *W, Guard g) {
     const int nt = (B.r + 15) / 16, gx = B.npad / 64, ks = B.ksplit, krange = B.npad / ks;
@@ -1905,6 +2033,11 @@ void constr_val(lorads_hip_ctx *c, Block &B, const double *X, const double *Y, d
                 Guard g) {
     if (B.nrow == 0) return;
     const bool uv = (X == c->U + B.off && Y == c->V + B.off);
+    if (B.use_cw) { // one kernel, no pair-dot array; for (U, V) the values are kept as the operator's weights
+        cw(c, B, X, Y, scale, uv ? B.w_uv : (double *)nullptr, cv, mode, vec, g);
+        if (uv) B.t_uv_valid = true;
+        return;
+    }
     double *T = uv ? B.T : B.T2;
     pairdots(c, B.pa, X, Y, B.r, T, g);
     if (uv) B.t_uv_valid = true;
@@ -1932,6 +2065,17 @@ int apply_operator(lorads_hip_ctx *c, Block &B, const double *V, const double *x
         grid = op_diag(c, B, V, mode, x, rhs, out, part, g);
     } else if (B.entry_only) {
         grid = op_entry(c, B, V, mode, x, rhs, out, part, g);
+    } else if (B.use_cw) {
+        // x and V are this cone's (U,V) in either order and B.w_uv already holds A(sym(U V^T))
+        const bool is_uv = (x == c->U + B.off && V == c->V + B.off) || (x == c->V + B.off && V == c->U + B.off);
+        const double *w = B.w_uv;
+        if (!(is_uv && B.t_uv_valid)) {
+            cw(c, B, x, V, 1.0, is_uv ? B.w_uv : B.w_op, (double *)nullptr, (int)CV_SET, (double *)nullptr, g);
+            w = is_uv ? B.w_uv : B.w_op;
+            B.t_uv_valid = is_uv;
+        }
+        if (samp) { e2 = c->ev_pool[c->ev_next++]; hipEventRecord(e2, c->stream); }
+        grid = spmm_cw(c, B, w, V, mode, x, rhs, out, part, g);
     } else {
         // x and V are this cone's (U,V) in either order and B.T already holds their pair dots
         const bool is_uv = (x == c->U + B.off && V == c->V + B.off) || (x == c->V + B.off && V == c->U + B.off);
@@ -2038,11 +2182,33 @@ void refresh_after_solve(lorads_hip_ctx *c, Block &B, const int *need) {
     constr_val(c, B, c->U + B.off, c->V + B.off, 1.0, B.cv, CV_DELTA, c->csum, Guard{nullptr, need});
 }
 
+// copy [word0, word0 + nwords) of the control block to its pinned mirror and wait for it
+int publish_and_wait(lorads_hip_ctx *c, size_t word0, size_t nwords) {
+    if (!c->use_publish) {
+        HC(hipMemcpyAsync(c->h_ctrl + 8 * word0, c->ctrl + 8 * word0, 8 * nwords, hipMemcpyDeviceToHost, c->stream));
+        HC(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const unsigned long long seq = ++c->pub_seq;
+    LAUNCH(k_publish, 1, (const unsigned long long *)c->ctrl + word0, (int)nwords, (unsigned long long *)c->h_ctrl_dev + word0,
+           c->h_flag_dev, seq);
+    volatile unsigned long long *f = c->h_flag;
+    for (unsigned long spins = 0;; ++spins) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((spins & 0xfffff) == 0xfffff) { // every ~million spins: is the stream still alive?
+            hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) { // everything ran: the flag must be there
+                if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return 0;
+                HC(hipStreamSynchronize(c->stream));
+                if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) return 0;
+                return fail_msg("result hand-over: sequence number not published");
+            }
+            if (q != hipErrorNotReady) return fail("hipStreamQuery", q);
+        }
+    }
+}
 int read_states(lorads_hip_ctx *c) {
-    HC(hipMemcpyAsync(c->h_ctrl, c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)(2 * c->nb), hipMemcpyDeviceToHost,
-                      c->stream));
-    HC(hipStreamSynchronize(c->stream));
-    return 0;
+    return publish_and_wait(c, 0, (64 * sizeof(double) + sizeof(CGState) * (size_t)(2 * c->nb)) / 8);
 }
 
 Solve make_solve(lorads_hip_ctx *c, int k, int half, const int *need) {
@@ -2104,7 +2270,11 @@ void enqueue_sweep(lorads_hip_ctx *c, int first, int resume_iter, double rho, do
         if (eval_follows && stg == 2 * c->nb - 1) {
             // the evaluation that follows overwrites constrVal / constrValSum with A(R R^T) (Q1): after the very last
             // solve only the pair dots are kept (the next sweep's first residual re-uses them)
-            if (!B.diag_only && !B.entry_only) { // (those operators never read the pair dots)
+            if (B.use_cw) {
+                cw(c, B, c->U + B.off, c->V + B.off, 1.0, B.w_uv, (double *)nullptr, (int)CV_SET, (double *)nullptr,
+                   Guard{nullptr, &s.st->done});
+                B.t_uv_valid = true;
+            } else if (!B.diag_only && !B.entry_only) { // (those operators never read the pair dots)
                 pairdots(c, B.pa, c->U + B.off, c->V + B.off, B.r, B.T, Guard{nullptr, &s.st->done});
                 B.t_uv_valid = true;
             }
@@ -2181,7 +2351,11 @@ int read_scalars_at(lorads_hip_ctx *c, const double *dptr, int count, double *ou
     memcpy(out, c->h_scal + 32, sizeof(double) * (size_t)count);
     return 0;
 }
-int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) { return read_scalars_at(c, c->scal + first, count, out); }
+int read_scalars(lorads_hip_ctx *c, int first, int count, double *out) { // scal[first .. first+count)
+    if (publish_and_wait(c, (size_t)first, (size_t)count)) return 1;
+    memcpy(out, c->h_scal + first, sizeof(double) * (size_t)count);
+    return 0;
+}
 
 // flat dot -> device scalar slot (+ cross-rank sum)
 int dot_to_slot(lorads_hip_ctx *c, const double *x, const double *y, int slot) {
@@ -2276,7 +2450,11 @@ void enqueue_batched(lorads_hip_ctx *c, int phase, int resume, double rho, doubl
         }
         // constrVal <- A(sym(U V^T)), constrValSum += new - old for every cone at once
         if (eval_follows && half == 1) { // dead before the evaluation (see enqueue_sweep): keep the pair dots only
-            if (!M.diag_only && !M.entry_only) {
+            if (M.use_cw) {
+                cw(c, M, c->U, c->V, 1.0, M.w_uv, (double *)nullptr, (int)CV_SET, (double *)nullptr,
+                   Guard{nullptr, &c->phase_done[half]});
+                M.t_uv_valid = true;
+            } else if (!M.diag_only && !M.entry_only) {
                 pairdots(c, M.pa, c->U, c->V, M.r, M.T, Guard{nullptr, &c->phase_done[half]});
                 M.t_uv_valid = true;
             }
@@ -2389,7 +2567,12 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
         lorads_hip_destroy(c);
         return 1;
     }
-    HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
+    HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1), hipHostMallocMapped));
+    HC(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocMapped));
+    *c->h_flag = 0;
+    HC(hipHostGetDevicePointer((void **)&c->h_ctrl_dev, c->h_ctrl, 0));
+    HC(hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0));
+    c->use_publish = !getenv("LORADS_NO_PUBLISH");
     c->scal = (double *)c->ctrl;
     c->st = (CGState *)(c->ctrl + 64 * sizeof(double));
     c->h_scal = (double *)c->h_ctrl;
@@ -2418,7 +2601,8 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a);
+        hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
     }
@@ -2428,6 +2612,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
+    if (c->h_flag) hipHostFree(c->h_flag);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2906,7 +3091,7 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
 int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
     const Block &B = c->blk[k];
-    *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.has_gram ? 0 : 1;
+    *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.use_cw ? 4 : B.has_gram ? 0 : 1;
     return 0;
 }
 

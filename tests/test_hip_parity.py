@@ -479,3 +479,24 @@ def test_every_rank_shape_vs_oracle(built, name, ranks):
         finally:
             hs.close()
             os_.close()
+
+
+@pytest.mark.parametrize("name", ["rand120", "coupled3x70", "theta30", "mix4", "densec40", "sdplp40"])
+def test_constraint_wise_operator_vs_reference_golden(built, name):
+    """The constraint-wise operator (k_cw: one wavefront per constraint forms A_i(sym(x V^T)) straight from the factors;
+    k_spmm<CW>: slot coefficient a * w_i) is chosen automatically for cones with >= 256 moderate-size constraints (the
+    headline configuration); here it is forced on the small golden instances and replayed against the reference's
+    vectors, function by function, like test_trace_vs_reference_golden."""
+    os.environ["LORADS_OP_CW"] = "1"
+    try:
+        g = common.golden_trace(name)
+        s = common.hip_session(common.instance_path(name))
+        try:
+            kinds = {s.hip_operator_kind(k) for k in range(s.nblk)}
+            assert "k_cw+k_spmm<CW>" in kinds, kinds
+            log = common.replay_trace(s, g, rtol=1e-9, resync=True)
+            assert len(log) > 50
+        finally:
+            s.close()
+    finally:
+        os.environ.pop("LORADS_OP_CW", None)
