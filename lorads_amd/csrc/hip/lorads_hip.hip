@@ -207,14 +207,16 @@ __global__ __launch_bounds__(TPB) void k_cw(int nrow, const int *__restrict__ a_
                                             const double *__restrict__ X,
                                             const double *__restrict__ Y, int r, double scale, double *__restrict__ w_out,
                                             double *__restrict__ cv, int mode, const int *__restrict__ row_idx,
-                                            double *__restrict__ vec, Guard g) {
+                                            double *__restrict__ vec, Guard g, int ell_w) {
     const bool live = !blocked(g);
     constexpr int GR = 64 / LG; // entry groups per wavefront
     const int i = (blockIdx.x * TPB + threadIdx.x) >> 6, lane64 = threadIdx.x & 63;
     const int grp = lane64 / LG, lane = lane64 % LG;
     const bool act = i < nrow;
     const int ic = act ? i : 0;
-    const int t0 = a_ptr[ic], t1 = act ? a_ptr[ic + 1] : t0;
+    // ell_w > 0: the entry arrays are padded to ell_w per constraint (a = 0 in the padding) -- no row-pointer load
+    // heads the dependent-load chain
+    const int t0 = ell_w ? ic * ell_w : a_ptr[ic], t1 = !act ? t0 : ell_w ? t0 + ell_w : a_ptr[ic + 1];
     // two entries per group and trip: the (row, col, a) of both are fetched before the first row gather (rows and
     // columns are stored per constraint entry -- no detour through the pattern entry)
     double acc = 0.0;
@@ -1376,6 +1378,8 @@ struct Block {
     bool use_cw = false;      // operator = k_cw (constraint values from the factors) + k_spmm<CW> (slot coefficient a w_i)
     int *cadj_ptr = nullptr, *cadj_col = nullptr, *cadj_con = nullptr; // row -> (neighbour, compact constraint, a)
     int *ca_row = nullptr, *ca_col = nullptr; // (row, col) of every constraint entry, in constraint-CSR order
+    double *ca_val = nullptr;                 // ... and its coefficient; all three padded to ca_ell per constraint when ca_ell > 0
+    int ca_ell = 0;
     double *cadj_a = nullptr;
     double *w_uv = nullptr, *w_op = nullptr; // A(sym(U V^T)) kept for re-use (valid <=> t_uv_valid); operator scratch
     bool is_lp = false;       // the LP block: generic diagonal cone everywhere except the ADMM update (k_lp_sweep)
@@ -1683,7 +1687,18 @@ int build_block(lorads_hip_ctx *c, Block &B, const lorads_hip_block &hb) {
                 for (int k = s0; k < s1; ++k) { col[k] = std::get<0>(tmp[k - s0]); con[k] = std::get<1>(tmp[k - s0]); av[k] = std::get<2>(tmp[k - s0]); }
             }
             std::vector<int> car(hb.a_row, hb.a_row + B.na), cac(hb.a_col, hb.a_col + B.na);
-            if (upload(&B.ca_row, car) || upload(&B.ca_col, cac) ||
+            std::vector<double> cav(hb.a_val, hb.a_val + B.na);
+            if (maxsz <= 32 && (double)hb.nrow * maxsz <= 1.5 * (double)B.na && !getenv("LORADS_NO_ELL")) {
+                // constraints of (nearly) equal size: fixed-width layout, padding = (row 0, row 0, 0.0)
+                B.ca_ell = maxsz;
+                car.assign((size_t)hb.nrow * maxsz, 0); cac.assign((size_t)hb.nrow * maxsz, 0); cav.assign((size_t)hb.nrow * maxsz, 0.0);
+                for (int i = 0; i < hb.nrow; ++i)
+                    for (int t = hb.a_ptr[i]; t < hb.a_ptr[i + 1]; ++t) {
+                        const size_t w = (size_t)i * maxsz + (size_t)(t - hb.a_ptr[i]);
+                        car[w] = hb.a_row[t]; cac[w] = hb.a_col[t]; cav[w] = hb.a_val[t];
+                    }
+            }
+            if (upload(&B.ca_row, car) || upload(&B.ca_col, cac) || upload(&B.ca_val, cav) ||
                 upload(&B.cadj_ptr, ptr) || upload(&B.cadj_col, col) || upload(&B.cadj_con, con) || upload(&B.cadj_a, av) ||
                 dalloc(&B.w_uv, (size_t)B.nrow) || dalloc(&B.w_op, (size_t)B.nrow))
                 return 1;
@@ -1969,8 +1984,8 @@ void cw(lorads_hip_ctx *c, const Block &B, const double *X, const double *Y, dou
     if (B.nrow == 0) return;
     const Shape sh = shape_for(B.r);
     const int grid = nblocks_for((size_t)B.nrow, TPB / 64);
-    SHAPE_DISPATCH(sh, LAUNCH((k_cw<LG_, V2_, NS_>), grid, B.nrow, B.a_ptr, B.ca_row, B.a_val, B.ca_col, X, Y, B.r, scale,
-                              w_out, cv, mode, B.row_idx, vec, g));
+    SHAPE_DISPATCH(sh, LAUNCH((k_cw<LG_, V2_, NS_>), grid, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, X, Y, B.r, scale,
+                              w_out, cv, mode, B.row_idx, vec, g, B.ca_ell));
 }
 // W = C X on the matrix cores (dense objective only)
 int dense_cx(lorads_hip_ctx *c, const Block &B, const double *X, double *W, Guard g) {
@@ -2601,7 +2616,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
