@@ -44,6 +44,11 @@ ks = out["kernels"]
 if "k_op_diag" in ks:
     op = ks["k_op_diag"]["read_bytes_median"] + ks["k_op_diag"]["write_bytes_mean"]
     out["cg_operator_application"] = {"kernels": ["k_op_diag"], "traffic_bytes": op}
+elif "k_cw" in ks and "k_spmm" in ks:
+    # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm<CW> (the more frequent k_spmm
+    # population -> median)
+    op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_cw", "k_spmm"))
+    out["cg_operator_application"] = {"kernels": ["k_cw", "k_spmm"], "traffic_bytes": op}
 elif "k_spmm" in ks:
     # the CG operator uses the A-pattern adjacency (the smaller of the two k_spmm populations -> median)
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_pairdots", "k_sgram", "k_spmm") if k in ks)
