@@ -363,8 +363,8 @@ def test_alm_front_and_step_function_level(built):
         assert x == y
 
 
-@pytest.mark.parametrize("name", ["blk4x60", "mix4"])
-def test_lockstep_sweep_equals_cone_by_cone(built, name):
+@pytest.mark.parametrize("name,grow", [("blk4x60", 0), ("mix4", 0), ("mix4", 13), ("blk4x60", 34)])
+def test_lockstep_sweep_equals_cone_by_cone(built, name, grow):
     """Block-separable cones of equal rank are swept in lockstep on the merged cone (one launch chain for all cones,
     per-cone CG scalars).  Against the cone-by-cone sweep (LORADS_NO_BATCH) on the same state: same CG iteration
     counts per ADMM iteration, factors equal to rounding (the per-cone partial sums are taken in another order)."""
@@ -373,12 +373,21 @@ def test_lockstep_sweep_equals_cone_by_cone(built, name):
     sessions = [common.hip_session(path), common.hip_session(path)]
     try:
         rank_warm = [int(x) for x in g["rank_warm"]]
+        rng = np.random.default_rng(99)
+        extra = {}
         for s in sessions:
             if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
                 s.be.resize_rank(rank_warm)
+            if grow:  # AUG_RANK in mid-flight: the merged view, its chunk tables and the row kernels' shapes follow the rank
+                s.be.resize_rank([grow] * s.nblk)
             for k in range(s.nblk):
                 n, r = s.block_shape(k)
-                s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+                R = g["R_warm_0_%d" % k].reshape(rank_warm[k], n).T
+                if grow:
+                    if k not in extra:
+                        extra[k] = 0.05 * rng.standard_normal((n, grow - rank_warm[k]))
+                    R = np.hstack([R, extra[k]])
+                s.be.set_mat(host.MAT_R, k, R)
             s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
             s.be.alm_to_admm()
             s.be.init_constr(host.PAIR_UV)
