@@ -46,6 +46,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -220,11 +223,18 @@ struct Ring {
 
 } // namespace
 
+constexpr size_t LZ_PINNED = 256; // doubles of pinned read-back per Lanczos worker (covers ncv <= 126)
+struct LzWorker {
+    hipStream_t stream = nullptr; // nullptr: the context's own stream (the first worker of a one-thread run)
+    double *pinned = nullptr;
+};
+
 struct lorads_hip_ctx {
     int m = 0, nb = 0, L = 2;
     double b_nrm1 = 0;
     hipStream_t stream = nullptr;
     std::vector<Block> blk;
+    std::vector<LzWorker> lz_workers; // dual-infeasibility eigen-solves (lanczos.inc)
     Block merged;             // all cones as ONE block-diagonal cone (see build_merged); valid when has_merged
     bool has_merged = false;
     std::vector<int> seg_row0_h;              // padded first row of every cone in the merged cone (+ end)
@@ -367,6 +377,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->h_flag) hipHostFree(c->h_flag);
+    for (auto &w : c->lz_workers) { if (w.stream) hipStreamDestroy(w.stream); if (w.pinned) hipHostFree(w.pinned); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
