@@ -737,7 +737,11 @@ int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
 
 int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
     c->ls_np = 0;
-    for (auto &B : c->blk) {
+    std::vector<Block *> all;
+    for (auto &B0 : c->blk) all.push_back(&B0);
+    if (c->merged_ok) all.push_back(&c->merged); // the merged cone carries its own copy of the objective
+    for (Block *bp : all) {
+        Block &B = *bp;
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
         if (B.dense_c) LAUNCH(k_scale, grid1d((size_t)B.npad * B.npad), (size_t)B.npad * B.npad, s, B.Cfull);

@@ -509,3 +509,47 @@ def test_constraint_wise_operator_vs_reference_golden(built, name):
             s.close()
     finally:
         os.environ.pop("LORADS_OP_CW", None)
+
+
+@pytest.mark.parametrize("name", ["mix4", "blk4x60", "sdplp40", "densec40"])
+def test_objective_scaling_reaches_every_copy(built, name):
+    """objScale_dualvar (data/lorads_solver.c:1040-1052) scales C and lambda in place; the device keeps C in several
+    images (per-cone lists, union-pattern base, dense matrix, LP costs, the merged multi-cone view): after scale_obj
+    every evaluation must agree with the oracle -- a stale copy showed up as a 5x (125x after three reopt rounds) too
+    small objective on separable multi-cone problems."""
+    hs, os_ = _pair(common.instance_path(name))
+    try:
+        rng = np.random.default_rng(11)
+        lam = 0.3 * rng.standard_normal(hs.m)
+        Rs = [rng.standard_normal(hs.block_shape(k)) / 3 for k in range(hs.nblk)]
+        vals = []
+        for s in (hs, os_):
+            be = s.be
+            for k in range(s.nblk):
+                be.set_mat(host.MAT_R, k, Rs[k])
+            be.set_vec(host.VEC_LAMBDA, lam)
+            be.scale_obj(5.0)
+            be.init_constr(host.PAIR_RR)
+            lag = be.alm_cal_grad(0.9)
+            po = be.cal_obj(host.PAIR_RR)
+            be.lbfgs_direction(0)
+            p1, p2 = be.alm_q12p12()
+            be.alm_to_admm()
+            be.init_constr(host.PAIR_UV)
+            if be.has_admm_step:
+                _, po2, do2, _ = be.admm_step(1.3, 1e-11, 800)
+            else:
+                be.admm_update_var(1.3, 1e-11, 800)
+                po2, do2 = be.cal_obj(host.PAIR_UV), be.cal_dual_obj()
+                be.update_dimacs(host.PAIR_UV)
+            di = be.dual_infeasibility()
+            vals.append((lag, po, p1, p2, po2, do2, di, be.get_vec(host.VEC_LAMBDA)))
+        a, b = vals
+        for i, key in enumerate(("lagNormSq", "pObj(RR)", "p1", "p2", "pObj(UV)", "dObj")):
+            # (the last two follow two inexact CG sweeps: equal to the CG tolerance, not to rounding)
+            assert a[i] == pytest.approx(b[i], rel=1e-7 if i < 4 else 2e-5, abs=1e-9), key
+        assert a[6] == pytest.approx(b[6], rel=2e-2, abs=1e-9), "dual infeasibility"
+        assert np.allclose(a[7], 5.0 * lam) and np.allclose(b[7], 5.0 * lam)
+    finally:
+        hs.close()
+        os_.close()
