@@ -553,3 +553,25 @@ def test_objective_scaling_reaches_every_copy(built, name):
     finally:
         hs.close()
         os_.close()
+
+
+_SWEEP = [dict(dyrankLevel=0), dict(dyrankLevel=3), dict(highAccMode=1), dict(lbfgsListLength=4), dict(reoptLevel=2, phase1Tol=1e-2),
+          dict(initRho=0.5), dict(timesLogRank=0.5), dict(timesLogRank=0.0), dict(phase2Tol=1e-7)]
+
+
+@pytest.mark.parametrize("name", ["mix4", "blk4x60", "sdplp40", "rand120", "theta50"])
+def test_whole_solve_option_sweep_vs_oracle(built, name):
+    """whole solves through the reference's command-line options that steer the outer loops (rank growth, reopt
+    rounds, high-accuracy mode, L-BFGS memory, start penalty, rank rule): both tables must end feasible at the same
+    objective.  (Iteration counts may differ: decisions sit on thresholds that rounding can cross.)"""
+    for params in _SWEEP:
+        res = []
+        for mk in (common.hip_session, common.oracle_session):
+            with mk(common.instance_path(name), **params) as s:
+                s.solve()
+                res.append(s.results())
+        h, o = res
+        assert h["constrVio1"] <= 2e-5 and o["constrVio1"] <= 2e-5, (params, h["constrVio1"], o["constrVio1"])
+        tol = max(2e-4, 10 * o["pdGap"], 10 * h["pdGap"])
+        assert abs(h["pObj"] - o["pObj"]) <= tol * (1 + abs(o["pObj"])), (params, h["pObj"], o["pObj"])
+        assert abs(h["dObj"] - o["dObj"]) <= 5 * tol * (1 + abs(o["dObj"])), (params, h["dObj"], o["dObj"])
