@@ -256,6 +256,8 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    bool final_pending = false;              // an evaluation's closing sums wait for the next hand-over (k_publish_final)
+    EvalFinalArgs final_args;
     double *scal = nullptr;   // 64 device scalars
     CGState *st = nullptr;    // one per (cone, half)
     CGState *h_st = nullptr;  // pinned mirror
