@@ -360,8 +360,10 @@ def main():
     dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or os.environ.get("LORADS_FORCE_DIST") == "1":  # (the knob measures the hook's own cost on one rank)
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
