@@ -575,3 +575,40 @@ def test_whole_solve_option_sweep_vs_oracle(built, name):
         tol = max(2e-4, 10 * o["pdGap"], 10 * h["pdGap"])
         assert abs(h["pObj"] - o["pObj"]) <= tol * (1 + abs(o["pObj"])), (params, h["pObj"], o["pObj"])
         assert abs(h["dObj"] - o["dObj"]) <= 5 * tol * (1 + abs(o["dObj"])), (params, h["dObj"], o["dObj"])
+
+
+def test_operator_variants_agree_fullsize(built):
+    """BASELINE-size cone (n = 20000, r = 40, 5000 constraints): the constraint-wise operator (k_cw + k_spmm<CW>, chosen
+    automatically here) and the pair-dot/Gram operator (k_pairdots + k_sgram + k_spmm) are two implementations of
+    x + A_V^*(A_V x); the same ADMM sweeps through either must give the same factors (CG driven to 1e-12)."""
+    path = _gen("rand20000")
+    rng = np.random.default_rng(21)
+    R0 = rng.standard_normal((20000, 40)) / np.sqrt(20000)
+    lam0 = 0.05 * rng.standard_normal(5000)
+    res = []
+    for cw in ("1", "0"):
+        os.environ["LORADS_OP_CW"] = cw
+        try:
+            s = common.hip_session(path, timesLogRank=4.0)
+        finally:
+            os.environ.pop("LORADS_OP_CW", None)
+        try:
+            assert s.hip_operator_kind(0) == ("k_cw+k_spmm<CW>" if cw == "1" else "k_pairdots+k_sgram+k_spmm")
+            be = s.be
+            be.set_mat(host.MAT_R, 0, R0)
+            be.set_vec(host.VEC_LAMBDA, lam0)
+            be.alm_to_admm()
+            be.init_constr(host.PAIR_UV)
+            its = []
+            for _ in range(3):
+                c, pobj, dobj, err1 = be.admm_step(50.0, 1e-12, 800)
+                be.update_dual_var(50.0)
+                its.append(c)
+            res.append((its, pobj, dobj, err1, be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0)))
+        finally:
+            s.close()
+    (ia, pa, da, ea, Ua, Va), (ib, pb, db, eb, Ub, Vb) = res
+    assert all(abs(x - y) <= 2 for x, y in zip(ia, ib)), (ia, ib)
+    assert pa == pytest.approx(pb, rel=1e-8) and da == pytest.approx(db, rel=1e-8) and ea == pytest.approx(eb, rel=1e-6)
+    assert np.allclose(Ua, Ub, rtol=0, atol=1e-8 * np.abs(Ub).max())
+    assert np.allclose(Va, Vb, rtol=0, atol=1e-8 * np.abs(Vb).max())
