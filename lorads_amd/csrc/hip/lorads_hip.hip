@@ -446,6 +446,7 @@ int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
 }
 
 int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
+    c->merged.t_uv_valid = false;
     for (auto &B : c->blk) B.t_uv_valid = false; // U is overwritten by the direction D
     const size_t n = c->all_elem;
     const int gv = c->ar ? grid1d(n) : grid_lbfgs(n);
@@ -758,6 +759,7 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
     if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
     Block &B = c->blk[k];
     B.t_uv_valid = false;
+    c->merged.t_uv_valid = false; // (its pair values of (U, V) cover this cone too)
     std::vector<double> rm((size_t)B.n * B.r);
     for (int j = 0; j < B.r; ++j)
         for (int i = 0; i < B.n; ++i) rm[(size_t)i * B.r + j] = cm[(size_t)j * B.n + i];

@@ -612,3 +612,35 @@ def test_operator_variants_agree_fullsize(built):
     assert pa == pytest.approx(pb, rel=1e-8) and da == pytest.approx(db, rel=1e-8) and ea == pytest.approx(eb, rel=1e-6)
     assert np.allclose(Ua, Ub, rtol=0, atol=1e-8 * np.abs(Ub).max())
     assert np.allclose(Va, Vb, rtol=0, atol=1e-8 * np.abs(Vb).max())
+
+
+def test_set_mat_invalidates_cached_pair_values(built):
+    """The constraint values of (U, V) are cached for the next solve's initial residual (per cone and on the merged
+    cone).  Overwriting a factor through the ABI must drop them: two sweeps, U replaced in between, against the
+    oracle doing the same."""
+    for name in ("mix4", "rand120"):
+        g = common.golden_trace(name)
+        hs, os_ = _pair(common.instance_path(name))
+        try:
+            rng = np.random.default_rng(5)
+            newU = [0.3 * rng.standard_normal(hs.block_shape(k)) for k in range(hs.nblk)]
+            out = []
+            for s in (hs, os_):
+                for k in range(s.nblk):
+                    n, r = s.block_shape(k)
+                    s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(int(g["rank_warm"][k]), n).T[:, :r])
+                s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+                s.be.alm_to_admm()
+                s.be.init_constr(host.PAIR_UV)
+                rho = float(g["admm_rho"][0])
+                s.be.admm_update_var(rho, 1e-11, 800)   # leaves cached pair values of the final (U, V)
+                for k in range(s.nblk):
+                    s.be.set_mat(host.MAT_U, k, newU[k])  # ... which are stale now
+                s.be.init_constr(host.PAIR_UV)
+                s.be.admm_update_var(rho, 1e-11, 800)
+                out.append([s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)] + [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)])
+            for x, y in zip(*out):
+                assert np.allclose(x, y, rtol=0, atol=1e-7 * max(1.0, np.abs(y).max()))
+        finally:
+            hs.close()
+            os_.close()
