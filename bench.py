@@ -320,6 +320,11 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
             try:
                 cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)
                 cb["host_cores_total"] = os.cpu_count()
+                try:
+                    with open("/proc/cpuinfo") as fh:
+                        cb["host_cpu_model"] = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+                except Exception:  # noqa: BLE001
+                    cb["host_cpu_model"] = None
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
             except Exception as e:  # noqa: BLE001
