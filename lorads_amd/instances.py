@@ -206,6 +206,25 @@ def sdp_lp(n, n_edges, n_extra, seed):
     return dict(m=n, blocks=[n, -d], b=np.ones(n), entries=ent)
 
 
+def coupled_lp(nblk, n_k, m, n_lp, seed):
+    """Coupled SDP cones (every A_i touches every cone) PLUS an LP block whose columns sit in two or three rows each:
+    the general path -- cone-by-cone Gauss-Seidel sweep, then the level-scheduled LP column sweep."""
+    base = coupled_blocks(nblk, n_k, m, seed, n_diag=1, n_off=2, r0=2, c_edges=2 * n_k)
+    rng = np.random.default_rng(seed + 5)
+    ent = list(base["entries"])
+    b = np.array(base["b"], dtype=np.float64)
+    for j in range(n_lp):
+        ent.append((0, nblk + 1, j + 1, j + 1, -float(0.1 + 0.3 * rng.random())))  # cost > 0
+        rows = rng.choice(m, size=int(rng.integers(2, 4)), replace=False)
+        x0 = float(rng.random())  # a feasible point exists with these LP values
+        for i in rows.tolist():
+            a = float(0.2 + 0.8 * rng.random())
+            ent.append((i + 1, nblk + 1, j + 1, j + 1, a))
+            b[i] += a * x0
+    ent.sort(key=lambda e: (e[0], e[1]))
+    return dict(m=m, blocks=list(base["blocks"]) + [-n_lp], b=b, entries=ent)
+
+
 def coupled_blocks(nblk, n_k, m, seed, n_diag=2, n_off=4, r0=3, c_edges=None):
     """Block-diagonal SDP whose constraints COUPLE the blocks: every A_i has entries in every
     block (dense-cone branch per block; Gauss-Seidel != Jacobi)."""
@@ -276,7 +295,8 @@ NAMED = {
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
     # SDP cone + LP block (slacks and coupling columns): the LP path (closed-form column sweep)
     "sdplp40": lambda: sdp_lp(40, 90, 12, 4001),
-    "sdpslack30": lambda: sdp_lp(30, 60, 0, 4002),         # slacks only: every LP column alone in its row (one level)
+    "sdpslack30": lambda: sdp_lp(30, 60, 0, 4002),
+    "coupledlp": lambda: coupled_lp(2, 40, 24, 18, 5100),   # coupled cones + LP columns across rows (general path)         # slacks only: every LP column alone in its row (one level)
     # timing / log-level instances
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
     "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini

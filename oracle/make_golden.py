@@ -39,6 +39,7 @@ TRACE = {
     "mix4": (8, 3, ["--phase1Tol", "1e-2"]),
     "sdplp40": (8, 3, ["--phase1Tol", "1e-2"]),
     "sdpslack30": (8, 3, ["--phase1Tol", "1e-2"]),
+    "coupledlp": (8, 3, ["--phase1Tol", "1e-2"]),
 }
 SOLVE = [
     ("maxcut100", ["--reoptLevel", "0"]),
@@ -55,6 +56,7 @@ SOLVE = [
     ("sdplp40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("sdplp40", ["--reoptLevel", "0"]),
     ("sdpslack30", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
+    ("coupledlp", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("maxcut800", ["--reoptLevel", "0"]),
     ("maxcut800", ["--reoptLevel", "0", "--phase1Tol", "1e-2"]),
 ]
