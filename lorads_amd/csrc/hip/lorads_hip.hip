@@ -19,16 +19,25 @@
 //   * C u A "union pattern" (PU) with transpose + adjacency, used by the RHS / gradient weighted-sum
 //     products (C + sum_i w_i A_i) X.
 //
+// Source layout: this file = context + the C ABI; kernels.inc = every kernel; build.inc = a cone's device image
+// (patterns, adjacency, Gram, operator variants, merged block-diagonal cone, LP block); sweep.inc = launch helpers,
+// the CG operator, speculative solves, the cone-by-cone and lockstep sweeps, the evaluation, result hand-over;
+// lanczos.inc = dual infeasibility.
+//
 // Kernels (HBM/L2-bound integer+FP64 gather work; bytes per unit in DESIGN.md):
 //   k_pairdots   T_e = X_p.Y_q + X_q.Y_p on a pattern            (reference LORADSUVt)
 //   k_cv         w_i = sum_k a_k T_e(k) (+ running-sum update)     (mul_inner_rk_double / coneAUV)
+//   k_cw         w_i straight from the factors, one wavefront per constraint (LORADSUVt + coneAUV)
 //   k_sval       S_e = [C_e] + sum_(i,a) weight_i a               (sdpDataWSum / addObjCoeff)
 //   k_sgram      S = G T                                          (coneAUV + sdpDataWSum fused)
-//   k_spmm       Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm)
+//   k_spmm       Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm); <CW>: S_e = a w_i
 //   k_op_diag    fused operator when every A_i = a e_p e_p^T (Max-Cut): one pass
-//   k_cg_*       CG vector updates with device-resident scalars   (CGSolve)
-//   k_eval_final ||b - sum||^2, b.lambda in one workgroup
-//   misc         averaging, dual update, line-search dots, L-BFGS axpy/dot
+//   k_op_entry   fused operator when every A_i holds one entry (matrix completion)
+//   k_dense_cx   W = C X for a dense objective on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   k_cg_*       CG vector updates with device-resident scalars   (CGSolve); *_seg: many cones in lockstep
+//   k_lbfgs_stage, k_pairdots_rd, k_cv_rd, k_obj_rd, k_alm_update, k_alm_tail, k_linesearch   phase 1
+//   k_lp_*       LP block: level-scheduled closed-form column sweep, column values, dual infeasibility
+//   k_eval_*, k_publish[_final]   closing sums of an evaluation, result hand-over to the host
 //
 // Launch structure: one ADMM iteration (2 CG solves per cone, constraint refreshes, objective,
 // DIMACS) is enqueued on one stream WITHOUT host round trips, using the iteration counts of the
