@@ -186,6 +186,9 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
             log_fn("cpu reference: %d ADMM its in %.2fs (setup+run wall %.1fs), %s CG its" % (its, sec, wall, kv["cg_iters"]))
             return {"value": its / sec, "unit": "ADMM iters/s", "cores": 1, "kind": "reference",
                     "cg_iters_per_s": int(kv["cg_iters"]) / sec,
+                    # where the reference stands after those iterations (compared with the device path below)
+                    "check": {"iterations": its, "cg_iters": int(kv["cg_iters"]), "pObj": float(kv["pObj"]),
+                              "dObj": float(kv["dObj"]), "err1": float(kv["err1"])},
                     "sample": "%d ADMM iterations (%s CG iterations) of the same workload from the same start state, "
                               "compiled reference (MKL sequential, 1 thread) on the host" % (its, kv["cg_iters"])}
         except Exception as e:  # noqa: BLE001
@@ -255,11 +258,13 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
     state_file = "/tmp/lorads_bench_state_%d.bin" % os.getpid()
     if rank == 0 and world == 1 and with_cpu:
         U, V = be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0)
+        lam0 = be.get_vec(host.VEC_LAMBDA)
         with open(state_file, "wb") as f:
             f.write(np.asfortranarray(U).tobytes(order="F"))
             f.write(np.asfortranarray(V).tobytes(order="F"))
-            f.write(be.get_vec(host.VEC_LAMBDA).tobytes())
+            f.write(lam0.tobytes())
         err1_start = err1
+        U0, V0 = U.copy(), V.copy()
 
     # ---- warm-up, then exactly K timed steps
     err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup, s)
@@ -327,6 +332,23 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
                     cb["host_cpu_model"] = None
                 out["cpu_baseline"] = cb
                 out["speedup_vs_cpu_1core"] = out["value"] / cb["value"]
+                chk = cb.pop("check", None)
+                if chk:
+                    # parity at the full size: the device path replays the same number of ADMM iterations from the very
+                    # state the reference started from (same rho, same tolerance rule) and must stand where it stands
+                    be.set_mat(host.MAT_U, 0, U0)
+                    be.set_mat(host.MAT_V, 0, V0)
+                    be.set_vec(host.VEC_LAMBDA, lam0)
+                    be.init_constr(host.PAIR_UV)
+                    be.cal_obj(host.PAIR_UV)
+                    e0 = be.update_dimacs(host.PAIR_UV)
+                    e1, cg1, p1, d1 = admm_steps(be, host, rho, e0, chk["iterations"], s)
+                    rel = lambda x, y: abs(x - y) / (1.0 + abs(y))  # noqa: E731
+                    out["parity_full_size"] = {
+                        "what": "%d ADMM iterations from the same (U, V, lambda), reference (CPU) vs this path (GPU)" % chk["iterations"],
+                        "pObj_ref": chk["pObj"], "pObj_gpu": p1 / 1.0, "pObj_rel_diff": rel(p1, chk["pObj"]),
+                        "dObj_ref": chk["dObj"], "dObj_gpu": d1 / 1.0, "dObj_rel_diff": rel(d1, chk["dObj"]),
+                        "err1_ref": chk["err1"], "err1_gpu": e1, "cg_iters_ref": chk["cg_iters"], "cg_iters_gpu": int(cg1)}
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
             finally:
