@@ -240,3 +240,22 @@ def exact_dual_infeasibility(prob, lam):
             tot += abs(min(e, 0.0))
             mins.append(e)
     return tot, mins
+
+
+def read_dump(path):
+    """records written by oracle/ref_driver.c: [int32 len][name][int64 n][n doubles]"""
+    import struct
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos < len(data):
+        (ln,) = struct.unpack_from("<i", data, pos)
+        pos += 4
+        name = data[pos:pos + ln].decode()
+        pos += ln
+        (n,) = struct.unpack_from("<q", data, pos)
+        pos += 8
+        out[name] = np.frombuffer(data, dtype="<f8", count=n, offset=pos).copy()
+        pos += 8 * n
+    return out

@@ -644,3 +644,73 @@ def test_set_mat_invalidates_cached_pair_values(built):
         finally:
             hs.close()
             os_.close()
+
+
+def test_fullsize_admm_vs_compiled_reference(built):
+    """BASELINE size (n = 20000, r = 40, m = 5000): the compiled reference (oracle/_ref, travels with the snapshot) and
+    the device path run the same 8 ADMM iterations from the same (U, V, lambda) -- the state after the device's own
+    phase 1 -- with the same rho and tolerance rule.  Objectives to 1e-10 relative, identical CG iteration count."""
+    drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref not built (it is compiled from /root/reference in the build container)")
+    path = _gen("rand20000")
+    s = common.hip_session(path, timesLogRank=4.0, phase1Tol=1e-2, reoptLevel=0)
+    try:
+        s.alm()
+        s.alm_to_admm()
+        be = s.be
+        res = s.results()
+        rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
+        U, V, lam = be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0), be.get_vec(host.VEC_LAMBDA)
+        state = "/tmp/lorads_test_state_%d.bin" % os.getpid()
+        with open(state, "wb") as f:
+            f.write(np.asfortranarray(U).tobytes(order="F"))
+            f.write(np.asfortranarray(V).tobytes(order="F"))
+            f.write(lam.tobytes())
+        its = 8
+        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+        r = subprocess.run([drv, path, "admmbench", "-", "--timesLogRank", "4.0", "--rho", repr(float(rho)), "--uv", state, "--nADMM",
+                            str(its)], env=env, capture_output=True, text=True, timeout=600)
+        os.remove(state)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("@@REF_ADMM_BENCH")]
+        assert r.returncode == 0 and line, r.stderr[-400:]
+        kv = dict(x.split("=") for x in line[0].split()[1:])
+        be.init_constr(host.PAIR_UV)
+        be.cal_obj(host.PAIR_UV)
+        e0 = be.update_dimacs(host.PAIR_UV)
+        e1, cg, pobj, dobj = s.admm_steps(its, rho, e0)
+        assert int(cg) == int(kv["cg_iters"])
+        assert pobj == pytest.approx(float(kv["pObj"]), rel=1e-10)
+        assert dobj == pytest.approx(float(kv["dObj"]), rel=1e-10)
+        assert e1 == pytest.approx(float(kv["err1"]), rel=1e-5)
+    finally:
+        s.close()
+
+
+@pytest.mark.skipif(os.environ.get("LORADS_SKIP_LONG_TESTS") == "1", reason="~20 s of reference CPU time per instance on the GPU box's host")
+@pytest.mark.parametrize("name", ["maxcut20000", "rand20000"])
+def test_fullsize_trace_vs_compiled_reference(built, name):
+    """Every lorads_func slot at BASELINE size (n = 20000, r = 40) against vectors the compiled reference produces on the
+    spot: oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
+    2 ADMM iterations), replayed through the C ABI exactly like the small golden traces."""
+    drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref not built")
+    path = _gen(name)
+    dump = "/tmp/lorads_test_trace_%d.bin" % os.getpid()
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", "2", "--timesLogRank", "4.0", "--phase1Tol", "1e-2"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-400:]
+    g = common.read_dump(dump)
+    os.remove(dump)
+    g["_nALM"] = np.array([3.0])
+    g["_nADMM"] = np.array([2.0])
+    s = common.hip_session(path, timesLogRank=4.0, phase1Tol=1e-2)
+    try:
+        assert s.block_shape(0) == (20000, 40)
+        log = common.replay_trace(s, g, rtol=1e-9, resync=True)
+        worst = max(e for _, e in log if not _[0:2] == "cg")
+        print(name, "records", len(log), "worst rel-to-scale error", worst)
+    finally:
+        s.close()
