@@ -688,10 +688,11 @@ def test_fullsize_admm_vs_compiled_reference(built):
 
 
 @pytest.mark.skipif(os.environ.get("LORADS_SKIP_LONG_TESTS") == "1", reason="~20 s of reference CPU time per instance on the GPU box's host")
-@pytest.mark.parametrize("name", ["maxcut20000", "rand20000"])
-def test_fullsize_trace_vs_compiled_reference(built, name):
-    """Every lorads_func slot at BASELINE size (n = 20000, r = 40) against vectors the compiled reference produces on the
-    spot: oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
+@pytest.mark.parametrize("name,tlr,shape", [("maxcut20000", 4.0, (20000, 40)), ("rand20000", 4.0, (20000, 40)),
+                                            ("blk16x4000", 2.0, (4000, 17))])
+def test_fullsize_trace_vs_compiled_reference(built, name, tlr, shape):
+    """Every lorads_func slot at BASELINE size (cfg3a, cfg3b: n = 20000, r = 40; cfg4: 16 cones n = 4000, the merged-cone /
+    lockstep path) against vectors the compiled reference produces on the spot: oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
     2 ADMM iterations), replayed through the C ABI exactly like the small golden traces."""
     drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver")
     if not os.path.exists(drv):
@@ -699,16 +700,16 @@ def test_fullsize_trace_vs_compiled_reference(built, name):
     path = _gen(name)
     dump = "/tmp/lorads_test_trace_%d.bin" % os.getpid()
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
-    r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", "2", "--timesLogRank", "4.0", "--phase1Tol", "1e-2"],
+    r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", "2", "--timesLogRank", repr(tlr), "--phase1Tol", "1e-2"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-400:]
     g = common.read_dump(dump)
     os.remove(dump)
     g["_nALM"] = np.array([3.0])
     g["_nADMM"] = np.array([2.0])
-    s = common.hip_session(path, timesLogRank=4.0, phase1Tol=1e-2)
+    s = common.hip_session(path, timesLogRank=tlr, phase1Tol=1e-2)
     try:
-        assert s.block_shape(0) == (20000, 40)
+        assert s.block_shape(0) == shape
         log = common.replay_trace(s, g, rtol=1e-9, resync=True)
         worst = max(e for _, e in log if not _[0:2] == "cg")
         print(name, "records", len(log), "worst rel-to-scale error", worst)
