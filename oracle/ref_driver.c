@@ -318,7 +318,9 @@ static int mode_trace(ctx_t *c, lorads_params *p, int n_alm, int n_admm, double 
      * (a cold ADMM start diverges and pins nothing); its result is dumped as an INPUT of the part */
     {
         double t0 = LUtilGetTimeStamp();
-        LORADS_ALMOptimize(p, S, &c->alm, p->maxALMIter, t0);
+        /* LORADS_REF_NO_WARM=1 (sizes where the reference's phase 1 takes hours): the ADMM part starts from the state
+         * the traced ALM iterations left -- still the same functions on the same inputs */
+        if (!getenv("LORADS_REF_NO_WARM")) LORADS_ALMOptimize(p, S, &c->alm, p->maxALMIter, t0);
         {
             double rkw[65];
             for (int k = 0; k < nb && k < 64; ++k) rkw[k] = S->var->R[k]->rank;
