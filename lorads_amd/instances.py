@@ -301,6 +301,8 @@ NAMED = {
     "maxcut800": lambda: maxcut(800, 19176, 8001),         # cfg2 G1-like
     "maxcut4000": lambda: maxcut(4000, 24000, 4000),       # cfg3a-mini
     "rand4000": lambda: randsparse(4000, 1000, 20001, c_edges=24000),  # cfg3b-mini
+    "matcomp4000": lambda: matcomp(2000, 2000, 16000, 5, 777),   # single-entry constraints at a size the reference solves
+    "sdplp2000": lambda: sdp_lp(2000, 8000, 300, 4100),            # SDP cone + 2300 LP columns
     # headline configs
     "maxcut20000": lambda: maxcut(20000, 120000, 20000),   # cfg3a
     "rand20000": lambda: randsparse(20000, 5000, 20001, c_edges=120000),  # cfg3b (headline bench)

@@ -689,7 +689,8 @@ def test_fullsize_admm_vs_compiled_reference(built):
 
 @pytest.mark.skipif(os.environ.get("LORADS_SKIP_LONG_TESTS") == "1", reason="~20 s of reference CPU time per instance on the GPU box's host")
 @pytest.mark.parametrize("name,tlr,shape", [("maxcut20000", 4.0, (20000, 40)), ("rand20000", 4.0, (20000, 40)),
-                                            ("blk16x4000", 2.0, (4000, 17))])
+                                            ("blk16x4000", 2.0, (4000, 17)), ("matcomp4000", 2.0, (4000, 17)),
+                                            ("sdplp2000", 2.0, (2000, 16))])
 def test_fullsize_trace_vs_compiled_reference(built, name, tlr, shape):
     """Every lorads_func slot at BASELINE size (cfg3a, cfg3b: n = 20000, r = 40; cfg4: 16 cones n = 4000, the merged-cone /
     lockstep path) against vectors the compiled reference produces on the spot: oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
@@ -699,7 +700,7 @@ def test_fullsize_trace_vs_compiled_reference(built, name, tlr, shape):
         pytest.skip("oracle/_ref not built")
     path = _gen(name)
     dump = "/tmp/lorads_test_trace_%d.bin" % os.getpid()
-    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", LORADS_REF_ALLOW_LP="1")
     r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", "2", "--timesLogRank", repr(tlr), "--phase1Tol", "1e-2"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-400:]
