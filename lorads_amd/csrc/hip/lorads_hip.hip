@@ -175,10 +175,11 @@ struct Pattern {              // one symmetric sparsity pattern with everything 
     double *e_val = nullptr;
     int *adj_ptr = nullptr, *adj_col = nullptr, *adj_e = nullptr; // row -> (neighbour, entry)
     double *S = nullptr;      // values on the pattern
+    double *S2 = nullptr;     // second image on the same pattern (fused front of a CG solve: sum_i w_i A_i); union pattern of k_cw cones only
     double *cbase = nullptr;  // C on the pattern (union pattern only)
     void release() {
         hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_val);
-        hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(S); hipFree(cbase);
+        hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(S); hipFree(S2); hipFree(cbase);
     }
 };
 
@@ -214,6 +215,9 @@ struct Block {
     double *ca_val = nullptr;                 // ... and its coefficient; all three padded to ca_ell per constraint when ca_ell > 0
     int ca_ell = 0;
     double *cadj_a = nullptr;
+    int cell_w = 0;                           // > 0: the slot list also in fixed width (8 or 16 per row) for k_spmm_ell
+    int *cell_col = nullptr, *cell_con = nullptr;
+    double *cell_a = nullptr;
     double *w_uv = nullptr, *w_op = nullptr; // A(sym(U V^T)) kept for re-use (valid <=> t_uv_valid); operator scratch
     bool is_lp = false;       // the LP block: generic diagonal cone everywhere except the ADMM update (k_lp_sweep)
     int lp_nlev = 0;
@@ -265,6 +269,7 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
     bool final_pending = false;              // an evaluation's closing sums wait for the next hand-over (k_publish_final)
     EvalFinalArgs final_args;
     double *scal = nullptr;   // 64 device scalars
@@ -279,6 +284,7 @@ struct lorads_hip_ctx {
     bool ar_stream_ordered = false; // the hook enqueues on our stream (RCCL): no host sync around it
     // profiling
     int prof = 0, prof_every = 8;
+    long n_sweeps = 0;        // ADMM sweeps run so far (cadence of the exact constraint refresh, see constr_by_recurrence)
     long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
     double ms_samp = 0, ms_samp_spmm = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_mv, pend_sp;
@@ -348,6 +354,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipHostGetDevicePointer((void **)&c->h_ctrl_dev, c->h_ctrl, 0));
     HC(hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0));
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
+    c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
+    c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
     c->st = (CGState *)(c->ctrl + 64 * sizeof(double));
     c->h_scal = (double *)c->h_ctrl;
@@ -376,7 +384,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);

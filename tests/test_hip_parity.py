@@ -614,6 +614,68 @@ def test_operator_variants_agree_fullsize(built):
     assert np.allclose(Va, Vb, rtol=0, atol=1e-8 * np.abs(Vb).max())
 
 
+@pytest.mark.parametrize("name,steps", [("rand120", 40), ("coupled3x70", 12), ("mix4", 12), ("sdplp40", 12)])
+def test_recurrence_and_fused_front_equal_two_pass_form(built, name, steps):
+    """k_cw cones keep A(sym(U V^T)) current through the CG updates (w += alpha A(sym(p V^T)), the operator's own
+    output) instead of re-gathering the factors after every solve, and build right-hand side + initial residual of a
+    solve in one pass (k_spmm2<FRONT>).  Both are re-arrangements of the same arithmetic: against the form that follows
+    the reference step by step (LORADS_EXACT_REFRESH=1 LORADS_SPLIT_FRONT=1: full constraint refresh after every solve,
+    separate passes) the sweeps must agree to rounding -- same CG iteration counts, factors to 1e-9 of their scale --
+    over enough sweeps to cross the periodic exact refresh (every 32nd), with tolerances that give 0, a few and > 20 CG
+    iterations per solve (restart path)."""
+    g = common.golden_trace(name)
+    os.environ["LORADS_OP_CW"] = "1"
+    res = []
+    try:
+        for exact in (False, True):
+            if exact:
+                os.environ["LORADS_EXACT_REFRESH"] = "1"
+                os.environ["LORADS_SPLIT_FRONT"] = "1"
+            try:
+                s = common.hip_session(common.instance_path(name))
+            finally:
+                os.environ.pop("LORADS_EXACT_REFRESH", None)
+                os.environ.pop("LORADS_SPLIT_FRONT", None)
+            try:
+                assert "k_cw+k_spmm<CW>" in {s.hip_operator_kind(k) for k in range(s.nblk)}
+                rank_warm = [int(x) for x in g["rank_warm"]]
+                if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                    s.be.resize_rank(rank_warm)
+                for k in range(s.nblk):
+                    n, r = s.block_shape(k)
+                    s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+                s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+                s.be.alm_to_admm()
+                s.be.init_constr(host.PAIR_UV)
+                rho = float(g["admm_rho"][0])
+                log = []
+                tols = [1e-8, 1e-3, 1e-13, 1e-6, 1e-1, 1e-10]
+                for it in range(steps):
+                    if it % 3 == 2:   # the slot-by-slot entry points take the same route
+                        c = s.be.admm_update_var(rho, tols[it % len(tols)], 800)
+                        p, d, e = s.be.cal_obj(host.PAIR_UV), s.be.cal_dual_obj(), s.be.update_dimacs(host.PAIR_UV)
+                    else:
+                        c, p, d, e = s.be.admm_step(rho, tols[it % len(tols)], 800)
+                    s.be.update_dual_var(rho)
+                    log.append((c, p, d, e))
+                res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)],
+                            [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)]))
+            finally:
+                s.close()
+    finally:
+        os.environ.pop("LORADS_OP_CW", None)
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    assert max(c for c, _, _, _ in lb) > 20, "no solve took the restart path"
+    for it, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x[0] - y[0]) <= max(1, 0.02 * y[0]), (it, "cg iterations", x[0], y[0])
+        assert x[1] == pytest.approx(y[1], rel=1e-8, abs=1e-10), (it, "pObj", x[1], y[1])
+        assert x[2] == pytest.approx(y[2], rel=1e-8, abs=1e-10), (it, "dObj", x[2], y[2])
+        assert x[3] == pytest.approx(y[3], rel=1e-6, abs=1e-12), (it, "err1", x[3], y[3])
+    for A, B in ((Ua, Ub), (Va, Vb)):
+        for x, y in zip(A, B):
+            assert np.allclose(x, y, rtol=0, atol=1e-8 * max(np.abs(y).max(), 1e-300))
+
+
 def test_set_mat_invalidates_cached_pair_values(built):
     """The constraint values of (U, V) are cached for the next solve's initial residual (per cone and on the merged
     cone).  Overwriting a factor through the ABI must drop them: two sweeps, U replaced in between, against the
