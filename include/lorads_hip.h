@@ -153,6 +153,9 @@ int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *ctx);
  *                sampled matvec launches, sampled matvec ms, spmm sampled launches, spmm sampled ms} */
 int lorads_hip_profile(lorads_hip_ctx *ctx, int32_t enable, int32_t sample_every);
 int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);
+/* Diagnostic (profiles/tools/ubench.py): `reps` back-to-back launches of kernel variant `which` on cone 0, elapsed
+ * milliseconds of all of them.  Overwrites the CG scratch vectors; the factors are left alone. */
+int lorads_hip_ubench(lorads_hip_ctx *ctx, int32_t which, int32_t reps, double *ms);
 /* algorithmic bytes of one CG operator application / one CG iteration of block blk */
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes_matvec, double *bytes_cg_iter);
 /* which kernels apply the CG operator of block blk: 0 = k_pairdots + k_sgram + k_spmm (Gram of the A_i),

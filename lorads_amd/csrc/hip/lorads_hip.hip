@@ -269,6 +269,7 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
     bool final_pending = false;              // an evaluation's closing sums wait for the next hand-over (k_publish_final)
     EvalFinalArgs final_args;
@@ -354,6 +355,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipHostGetDevicePointer((void **)&c->h_ctrl_dev, c->h_ctrl, 0));
     HC(hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0));
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
+    c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
@@ -875,6 +877,66 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
     s[5] = c->ms_samp;
     s[6] = (double)c->n_samp_spmm;
     s[7] = c->ms_samp_spmm;
+    return 0;
+}
+
+// Diagnostic: `reps` back-to-back launches of one kernel variant on cone 0 between two events (ms for all of them);
+// under rocprofv3 every variant shows up under its own name.  Inputs are the cone's U and V, outputs go to the CG
+// scratch vectors.  Only for the shape of the headline (r = 40); profiles/tools/ubench.py drives it.
+int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms) {
+    if (c->nb < 1) return fail_msg("ubench: no cone");
+    Block &B = c->blk[0];
+    if (B.r != 40 || !B.use_cw || !B.cell_w || !B.pu.S2) return fail_msg("ubench: needs a k_cw cone of rank 40");
+    const double *U = c->U + B.off, *V = c->V + B.off;
+    double *Q = c->cQ + B.off, *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;
+    const size_t len = (size_t)B.n * B.r;
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
+    HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
+    hipEvent_t e0, e1;
+    HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+    const int grow = nblocks_for((size_t)B.n, TPB / 8), gcw = nblocks_for((size_t)B.nrow, TPB / 64);
+    for (int it = -3; it < reps; ++it) { // three warm-up launches
+        if (it == 0) HC(hipEventRecord(e0, c->stream));
+        switch (which) {
+        case 0: LAUNCH((k_cw<8, true, 3>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op, (double *)nullptr,
+                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell); break;
+        case 1: LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
+                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell); break;
+        case 2:
+            if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
+                                      B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q,
+                                      part_slot(c, 0), NOGUARD);
+            else LAUNCH((k_spmm_ell<8, true, 3, 16>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col, B.cell_con,
+                        B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
+            break;
+        case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
+                       (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
+        case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, (const double *)B.pu.S2, V,
+                       B.r, 0, U, (const double *)nullptr, 1.0, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD,
+                       (const double *)nullptr); break;
+        case 5: LAUNCH((k_spmm2<8, true, 3, false>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, (const double *)nullptr, V,
+                       B.r, (int)OP_RHS, (const double *)nullptr, (const double *)nullptr, 1.0, rhs, (double *)nullptr, part_slot(c, 1),
+                       (double *)nullptr, NOGUARD, (const double *)nullptr); break;
+        case 6: case 7: case 8: case 9: { // k_cg_update with 2048 / 1024 / 512 / 256 workgroups (alpha = 0 / 1: arrays stay put)
+            const int gv = 2048 >> (which - 6);
+            LAUNCH(k_cg_update, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
+                   (const double *)nullptr, 0);
+        } break;
+        case 10: LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), 1024), B.nc, B.c_row, B.c_col, B.c_val, U, U,
+                        B.r, part_slot(c, 4), NOGUARD); break;
+        case 11: LAUNCH(k_sval, std::max(1, nblocks_for((size_t)B.pu.ne, TPB)), B.pu.ne, B.pu.e_ptr, B.pu.e_con, B.pu.e_val, B.pu.cbase,
+                        (int)W_COMPACT, WArgs{B.w_op, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0}, B.pu.S, NOGUARD,
+                        (CGState *)nullptr, 0, (const double *)B.w_op, B.pu.S2); break;
+        default: return fail_msg("ubench: unknown variant");
+        }
+    }
+    HC(hipEventRecord(e1, c->stream));
+    HC(hipEventSynchronize(e1));
+    float f = 0;
+    HC(hipEventElapsedTime(&f, e0, e1));
+    *ms = f;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    invalidate_t(c);
     return 0;
 }
 

@@ -343,6 +343,7 @@ class Session:
             lib.lorads_hip_profile_read.argtypes = [C.c_void_p, _dp]
             lib.lorads_hip_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
             lib.lorads_hip_sync.argtypes = [C.c_void_p]
+            lib.lorads_hip_ubench.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
             lib.lorads_hip_operator_kind.argtypes = [C.c_void_p, C.c_int, _ip]
             lib.lorads_hip_stream.restype = C.c_void_p
             lib.lorads_hip_stream.argtypes = [C.c_void_p]
@@ -364,6 +365,13 @@ class Session:
         keys = ["matvec_launches", "matvec_ms_est", "cg_iters", "cg_solves", "sampled", "sampled_ms", "spmm_sampled",
                 "spmm_sampled_ms"]
         return dict(zip(keys, [out[i] for i in range(8)]))
+
+    def hip_ubench(self, which, reps):
+        """milliseconds of `reps` back-to-back launches of kernel variant `which` (diagnostic, see lorads_hip.h)"""
+        lib, ctx = self._hip()
+        ms = C.c_double()
+        _check(lib.lorads_hip_ubench(ctx, int(which), int(reps), C.byref(ms)), "ubench")
+        return ms.value
 
     def hip_algorithmic_bytes(self, blk=0):
         lib, ctx = self._hip()
