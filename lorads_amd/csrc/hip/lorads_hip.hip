@@ -119,10 +119,46 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double *sh) {
     for (int k = 0; k < N; ++k) v[k] = (sh[k * 4] + sh[k * 4 + 1]) + (sh[k * 4 + 2] + sh[k * 4 + 3]);
     __syncthreads();
 }
-__device__ __forceinline__ double sum_partials(const double *part, int n, double *sh) {
+// this thread's share of n partial sums, part[tid], part[tid + TPB], ... added in that order.  Four loads are issued
+// per trip, unconditionally (clamped index, masked value): the plain loop `v += part[i]` compiles to one load + full
+// wait per trip, i.e. n / TPB memory round trips in a row at the head of every kernel that consumes partials
+__device__ __forceinline__ double private_partials(const double *__restrict__ part, int n) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += TPB) v += part[i];
-    return block_sum(v, sh);
+    for (int i = threadIdx.x; i < n; i += 4 * TPB) {
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = i + k * TPB;
+            t[k] = part[j < n ? j : i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += (i + k * TPB < n) ? t[k] : 0.0;
+    }
+    return v;
+}
+__device__ __forceinline__ double sum_partials(const double *part, int n, double *sh) {
+    return block_sum(private_partials(part, n), sh);
+}
+// the same for N arrays at once (all 4 N loads of a trip in flight together); every pointer must be readable at [0]
+template <int N>
+__device__ __forceinline__ void private_partials_n(const double *const (&part)[N], const int (&n)[N], double (&v)[N]) {
+    int nmax = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) { v[a] = 0.0; nmax = n[a] > nmax ? n[a] : nmax; }
+    for (int i = threadIdx.x; i < nmax; i += 4 * TPB) {
+        double t[N][4];
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = i + k * TPB;
+                t[a][k] = part[a][j < n[a] ? j : 0];
+            }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[a] += (i + k * TPB < n[a]) ? t[a][k] : 0.0;
+    }
 }
 
 struct CGState {
@@ -140,11 +176,120 @@ struct Guard {
     const int *skip;
     const int *need;
 };
-__device__ __forceinline__ bool blocked(const Guard &g) { return (g.skip && *g.skip != 0) || (g.need && *g.need == 0); }
+// Split in two so that the gate words travel while the kernel issues its own loads: gate_load() at the top requests both
+// words at once, without a branch between them (a null pointer borrows the other word's address), GATE_OPEN looks at them
+// where the first predicated store needs the answer.  (`(skip && *skip) || (need && *need == 0)` at the top of a kernel
+// compiles to load - wait - branch - load - wait: two memory round trips before the kernel's first own load.)
+struct Gate { int vs, vn; };
+__device__ __forceinline__ Gate gate_load(const Guard &g) {
+    Gate t{0, 1};
+    if (g.skip || g.need) { // uniform: kernel arguments
+        const int *ps = g.skip ? g.skip : g.need, *pn = g.need ? g.need : g.skip;
+        t.vs = *ps;
+        t.vn = *pn;
+    }
+    return t;
+}
+__device__ __forceinline__ bool gate_blocked(const Guard &g, const Gate &t) { return (g.skip && t.vs != 0) || (g.need && t.vn == 0); }
+#define GATE_OPEN (!gate_blocked(g, gt))
+__device__ __forceinline__ bool blocked(const Guard &g) { return gate_blocked(g, gate_load(g)); }
 // The gate words were written by the previous kernel, so reading them costs a cache-missing scalar load
 // (~1.5 us when it heads the kernel).  Kernels therefore evaluate `live` first but only USE it to predicate
 // their stores: the gate loads fly together with the kernel's own first loads.  A blocked kernel computes on
 // whatever is there and writes nothing.
+
+// Scalar steps of CGSolve that ride on a neighbouring kernel instead of being one-workgroup launches of their own
+// (each such launch costs ~4.5 us + a boundary for a handful of flops):
+//  * InitArgs -- the start of a solve (k_cg_init: ||rhs||_1, ||r_0||, converged at once?) evaluated by the FIRST kernel of
+//    iteration 0 (k_cw): every workgroup sums the same partials in the same order and gates itself on the result,
+//    workgroup 0 writes the state for the kernels that follow.  Nothing of the old state is read, so there is no race.
+//  * Deferred -- the convergence test after an update (k_cg_check, CHK_ITER) evaluated by the kernel that FOLLOWS the
+//    update (k_cg_dir, k_refresh_w, k_average).  The test reads the state before it; that state is taken from `shadow`,
+//    a copy k_cg_update (and the solve's init) leave behind, so that workgroup 0 can write the new state into `st`
+//    while the other workgroups are still reading.  Re-running a test whose update was skipped (solve already finished)
+//    reproduces the same state from the same shadow and partials.
+struct InitArgs {
+    CGState *st;              // nullptr: nothing to do
+    CGState *shadow;
+    const double *part_rr, *part_b;
+    int nrr, nb;
+    double tol;
+};
+struct Deferred {
+    CGState *st;              // nullptr: nothing pending
+    const CGState *shadow;
+    const double *part;       // partials of ||r||^2 left by the update
+    int np, maxit;
+    double tol;
+    const int *need;          // the solve's own gate (previous stage finished)
+};
+struct DefOut { int done; double beta; };
+__device__ __forceinline__ DefOut run_deferred(const Deferred &d, double *sh) {
+    const double rr_old = d.shadow->rr, bnorm = d.shadow->bnorm;
+    const int it0 = d.shadow->iter, done0 = d.shadow->done;
+    const double beta0 = d.shadow->beta;
+    const int needw = *(d.need ? d.need : &d.shadow->done); // (no branch around the load)
+    const bool open = !(d.need && needw == 0);
+    const double a = sum_partials(d.part, d.np, sh);
+    DefOut o;
+    if (!open) { o.done = 0; o.beta = 0.0; return o; }          // the whole stage is still gated: its words read 0
+    if (done0 != 0) { o.done = done0; o.beta = beta0; return o; } // finished before this test (e.g. at the initial residual)
+    const int it = it0 + 1;                                       // lorads_cgs.c:189-194, :217-224 (as k_cg_check)
+    o.beta = a / rr_old;
+    o.done = sqrt(a) / bnorm < d.tol ? 1 : (it >= d.maxit ? 3 : 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.st->iter = it;
+        if (a != a) d.st->nan = 1;
+        d.st->beta = o.beta;
+        d.st->rr = a;
+        if (o.done) d.st->done = o.done;
+    }
+    return o;
+}
+// gate of a kernel that carries a Deferred test: the word of the solve under test is the test's result, not memory
+__device__ __forceinline__ bool blocked_after(const Guard &g, const Deferred &d, int done_now) {
+    const int sk = g.skip ? (g.skip == &d.st->done ? done_now : *g.skip) : 0;
+    const int nd = g.need ? (g.need == &d.st->done ? done_now : *g.need) : 1;
+    return sk != 0 || nd == 0;
+}
+
+// k_cg_init in two halves for a carrier that wants its own loads in between: per-thread sums of the partials ...
+__device__ __forceinline__ void init_private(const InitArgs &ia, double (&iv)[2]) {
+    const double *const pp[2] = {ia.part_rr, ia.part_b};
+    const int nn[2] = {ia.nrr, ia.nb};
+    private_partials_n<2>(pp, nn, iv);
+}
+// ... and the workgroup reduction + decision (same sums as sum_partials); returns the solve's `done` word or -1 (gated)
+__device__ __forceinline__ int finish_init(const InitArgs &ia, bool open, double (&iv)[2], double *sh8) {
+    block_sum_n<2>(iv, sh8);
+    const bool conv = sqrt(iv[0]) / iv[1] < ia.tol;
+    if (!open) return -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CGState s;
+        s.rr = iv[0]; s.bnorm = iv[1]; s.beta = 0.0; s.iter = 0; s.nan = 0; s.pad = 0;
+        s.done = conv ? 2 : 0;
+        *ia.st = s;
+        *ia.shadow = s;
+    }
+    return conv ? 2 : 0;
+}
+// k_cg_init carried by the first kernel of iteration 0 (see InitArgs): returns the solve's `done` word, or -1 while the
+// stage is gated; every workgroup computes it, workgroup 0 writes the state
+__device__ __forceinline__ int run_init(const InitArgs &ia, const Guard &g, double *sh) {
+    const bool open = !(g.need && *g.need == 0);
+    const double a = sum_partials(ia.part_rr, ia.nrr, sh);
+    const double b = sum_partials(ia.part_b, ia.nb, sh);
+    const bool conv = sqrt(a) / b < ia.tol;
+    if (!open) return -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CGState s;
+        s.rr = a; s.bnorm = b; s.beta = 0.0; s.iter = 0; s.nan = 0; s.pad = 0;
+        s.done = conv ? 2 : 0;
+        *ia.st = s;
+        *ia.shadow = s;
+    }
+    return conv ? 2 : 0;
+}
 
 enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3 };
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
@@ -275,6 +420,12 @@ struct lorads_hip_ctx {
     EvalFinalArgs final_args;
     double *scal = nullptr;   // 64 device scalars
     CGState *st = nullptr;    // one per (cone, half)
+    CGState *st_shadow = nullptr; // state before a pending convergence test (see Deferred)
+    InitArgs pend_init{};     // a solve's start waiting for the kernel that will carry it (flushed as k_cg_init otherwise)
+    Guard pend_init_g{};
+    Deferred pend_chk{};      // a convergence test waiting likewise (flushed as k_cg_check otherwise)
+    Guard pend_chk_g{};
+    bool opt_lazy_scalars = true; // LORADS_LAZY_SCALARS=0: every scalar step as its own launch
     CGState *h_st = nullptr;  // pinned mirror
     double *h_scal = nullptr; // pinned mirror of scalars
     std::vector<Ring> ring;
@@ -355,6 +506,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipHostGetDevicePointer((void **)&c->h_ctrl_dev, c->h_ctrl, 0));
     HC(hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0));
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
+    c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
@@ -368,6 +520,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipMemset(c->scal, 0, sizeof(double) * 64));
     HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
     HC(hipMemset(c->st, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
+    if (dalloc(&c->st_shadow, (size_t)std::max(2 * c->nb, 1))) return 1;
+    HC(hipMemset(c->st_shadow, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
     HC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -393,7 +547,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
@@ -899,9 +1053,9 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
         if (it == 0) HC(hipEventRecord(e0, c->stream));
         switch (which) {
         case 0: LAUNCH((k_cw<8, true, 3>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op, (double *)nullptr,
-                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell); break;
+                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}); break;
         case 1: LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
-                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell); break;
+                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}); break;
         case 2:
             if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
                                       B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q,
@@ -920,7 +1074,7 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
         case 6: case 7: case 8: case 9: { // k_cg_update with 2048 / 1024 / 512 / 256 workgroups (alpha = 0 / 1: arrays stay put)
             const int gv = 2048 >> (which - 6);
             LAUNCH(k_cg_update, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
-                   (const double *)nullptr, 0);
+                   (const double *)nullptr, 0, c->st_shadow);
         } break;
         case 10: LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), 1024), B.nc, B.c_row, B.c_col, B.c_val, U, U,
                         B.r, part_slot(c, 4), NOGUARD); break;

@@ -676,6 +676,64 @@ def test_recurrence_and_fused_front_equal_two_pass_form(built, name, steps):
             assert np.allclose(x, y, rtol=0, atol=1e-8 * max(np.abs(y).max(), 1e-300))
 
 
+@pytest.mark.parametrize("name,cw", [("rand120", "1"), ("maxcut100", None), ("coupled3x70", "1"), ("mix4", None), ("sdplp40", "1")])
+def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built, name, cw):
+    """The start of a CG solve (k_cg_init) and the convergence test after an update (k_cg_check) normally ride on a
+    neighbouring kernel (k_cw; k_cg_dir / k_refresh_w / k_average): every workgroup re-derives the scalars from the same
+    partial sums in the same order, workgroup 0 publishes them.  LORADS_LAZY_SCALARS=0 launches them as the
+    one-workgroup kernels they replace.  Same arithmetic, so the sweeps must agree BIT FOR BIT -- iteration counts,
+    objectives, factors -- including speculation misses and solves of 0, few and > 20 iterations."""
+    g = common.golden_trace(name) if name != "maxcut100" else None
+    if cw:
+        os.environ["LORADS_OP_CW"] = cw
+    res = []
+    try:
+        for lazy in ("1", "0"):
+            os.environ["LORADS_LAZY_SCALARS"] = lazy
+            try:
+                s = common.hip_session(common.instance_path(name), phase1Tol=1e-2)
+            finally:
+                os.environ.pop("LORADS_LAZY_SCALARS", None)
+            try:
+                if g is not None:
+                    rank_warm = [int(x) for x in g["rank_warm"]]
+                    if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                        s.be.resize_rank(rank_warm)
+                    for k in range(s.nblk):
+                        n, r = s.block_shape(k)
+                        s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+                    s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+                    rho = float(g["admm_rho"][0])
+                else:
+                    rng = np.random.default_rng(11)
+                    n, r = s.block_shape(0)
+                    s.be.set_mat(host.MAT_R, 0, rng.standard_normal((n, r)))
+                    s.be.set_vec(host.VEC_LAMBDA, np.linspace(-1, 1, s.m))
+                    rho = 0.3
+                s.be.alm_to_admm()
+                s.be.init_constr(host.PAIR_UV)
+                log = []
+                tols = [1e-8, 1e-3, 1e-13, 1e-6, 1e-1, 1e-10]
+                for it in range(12):
+                    if it % 3 == 2:
+                        c = s.be.admm_update_var(rho, tols[it % len(tols)], 800)
+                        p, d, e = s.be.cal_obj(host.PAIR_UV), s.be.cal_dual_obj(), s.be.update_dimacs(host.PAIR_UV)
+                    else:
+                        c, p, d, e = s.be.admm_step(rho, tols[it % len(tols)], 800)
+                    s.be.update_dual_var(rho)
+                    log.append((c, p, d, e))
+                res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)],
+                            [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)]))
+            finally:
+                s.close()
+    finally:
+        os.environ.pop("LORADS_OP_CW", None)
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    assert la == lb, (la, lb)
+    for x, y in zip(Ua + Va, Ub + Vb):
+        assert np.array_equal(x, y)
+
+
 def test_set_mat_invalidates_cached_pair_values(built):
     """The constraint values of (U, V) are cached for the next solve's initial residual (per cone and on the merged
     cone).  Overwriting a factor through the ABI must drop them: two sweeps, U replaced in between, against the
