@@ -224,19 +224,25 @@ struct Deferred {
     const int *need;          // the solve's own gate (previous stage finished)
 };
 struct DefOut { int done; double beta; };
-__device__ __forceinline__ DefOut run_deferred(const Deferred &d, double *sh) {
-    const double rr_old = d.shadow->rr, bnorm = d.shadow->bnorm;
-    const int it0 = d.shadow->iter, done0 = d.shadow->done;
-    const double beta0 = d.shadow->beta;
-    const int needw = *(d.need ? d.need : &d.shadow->done); // (no branch around the load)
-    const bool open = !(d.need && needw == 0);
-    const double a = sum_partials(d.part, d.np, sh);
+// in two halves, like the carried start: the loads first (before the carrier's own), the decision where it is needed
+struct DefPriv { double rr_old, bnorm, beta0, a; int it0, done0, needw; };
+__device__ __forceinline__ DefPriv deferred_private(const Deferred &d) {
+    DefPriv v;
+    v.rr_old = d.shadow->rr; v.bnorm = d.shadow->bnorm; v.beta0 = d.shadow->beta;
+    v.it0 = d.shadow->iter; v.done0 = d.shadow->done;
+    v.needw = *(d.need ? d.need : &d.shadow->done); // (no branch around the load)
+    v.a = private_partials(d.part, d.np);
+    return v;
+}
+__device__ __forceinline__ DefOut finish_deferred(const Deferred &d, const DefPriv &v, double *sh) {
+    const bool open = !(d.need && v.needw == 0);
+    const double a = block_sum(v.a, sh);
     DefOut o;
-    if (!open) { o.done = 0; o.beta = 0.0; return o; }          // the whole stage is still gated: its words read 0
-    if (done0 != 0) { o.done = done0; o.beta = beta0; return o; } // finished before this test (e.g. at the initial residual)
-    const int it = it0 + 1;                                       // lorads_cgs.c:189-194, :217-224 (as k_cg_check)
-    o.beta = a / rr_old;
-    o.done = sqrt(a) / bnorm < d.tol ? 1 : (it >= d.maxit ? 3 : 0);
+    if (!open) { o.done = 0; o.beta = 0.0; return o; }                // the whole stage is still gated: its words read 0
+    if (v.done0 != 0) { o.done = v.done0; o.beta = v.beta0; return o; } // finished before this test (e.g. at the initial residual)
+    const int it = v.it0 + 1;                                           // lorads_cgs.c:189-194, :217-224 (as k_cg_check)
+    o.beta = a / v.rr_old;
+    o.done = sqrt(a) / v.bnorm < d.tol ? 1 : (it >= d.maxit ? 3 : 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.st->iter = it;
         if (a != a) d.st->nan = 1;
@@ -246,12 +252,19 @@ __device__ __forceinline__ DefOut run_deferred(const Deferred &d, double *sh) {
     }
     return o;
 }
+__device__ __forceinline__ DefOut run_deferred(const Deferred &d, double *sh) { return finish_deferred(d, deferred_private(d), sh); }
 // gate of a kernel that carries a Deferred test: the word of the solve under test is the test's result, not memory
 __device__ __forceinline__ bool blocked_after(const Guard &g, const Deferred &d, int done_now) {
     const int sk = g.skip ? (g.skip == &d.st->done ? done_now : *g.skip) : 0;
     const int nd = g.need ? (g.need == &d.st->done ? done_now : *g.need) : 1;
     return sk != 0 || nd == 0;
 }
+
+// what a kernel may carry: the start of a solve or a convergence test (never both)
+struct Carry {
+    InitArgs ia;
+    Deferred d;
+};
 
 // k_cg_init in two halves for a carrier that wants its own loads in between: per-thread sums of the partials ...
 __device__ __forceinline__ void init_private(const InitArgs &ia, double (&iv)[2]) {
@@ -1040,6 +1053,22 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
 int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms) {
     if (c->nb < 1) return fail_msg("ubench: no cone");
     Block &B = c->blk[0];
+    if (which >= 100) { // single-entry cones (matrix completion): the whole-operator kernels, any rank
+        if (!B.entry_only) return fail_msg("ubench: variants >= 100 need a single-entry cone");
+        hipEvent_t e0, e1;
+        HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+        for (int it = -3; it < reps; ++it) {
+            if (it == 0) HC(hipEventRecord(e0, c->stream));
+            op_entry(c, B, c->V + B.off, OP_CG, c->U + B.off, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
+        }
+        HC(hipEventRecord(e1, c->stream));
+        HC(hipEventSynchronize(e1));
+        float f = 0;
+        HC(hipEventElapsedTime(&f, e0, e1));
+        *ms = f;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        return 0;
+    }
     if (B.r != 40 || !B.use_cw || !B.cell_w || !B.pu.S2) return fail_msg("ubench: needs a k_cw cone of rank 40");
     const double *U = c->U + B.off, *V = c->V + B.off;
     double *Q = c->cQ + B.off, *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;

@@ -15,12 +15,18 @@ NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>",
          10: "k_obj", 11: "k_sval (two images)"}
 
 
+ENTRY = {100: "k_op_entry (whole operator, single-entry constraints)"}
+
+
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     which = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else sorted(NAMES)
-    path = bench.build_instance("rand20000", "/tmp/lorads_bench_rand20000.dat-s")
+    workload = sys.argv[3] if len(sys.argv) > 3 else "rand20000"
+    tlr = float(sys.argv[4]) if len(sys.argv) > 4 else 4.0
+    NAMES.update(ENTRY)
+    path = bench.build_instance(workload, "/tmp/lorads_bench_%s.dat-s" % workload)
     s = host.Session.open(path)
-    s.set_params(verbose=0, timesLogRank=4.0, phase1Tol=1e-2, reoptLevel=0)
+    s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
     s.prepare(1, 0)
     s.attach_hip()
     s.alm()

@@ -370,7 +370,13 @@ def test_lockstep_sweep_equals_cone_by_cone(built, name, grow):
     counts per ADMM iteration, factors equal to rounding (the per-cone partial sums are taken in another order)."""
     g = common.golden_trace(name)
     path = common.instance_path(name)
-    sessions = [common.hip_session(path), common.hip_session(path)]
+    # (the lockstep sweep builds right-hand side and initial residual in two passes; the cone-by-cone sweep is asked to
+    # do the same, so that what is compared is the sweep order and nothing else)
+    os.environ["LORADS_SPLIT_FRONT"] = "1"
+    try:
+        sessions = [common.hip_session(path), common.hip_session(path)]
+    finally:
+        os.environ.pop("LORADS_SPLIT_FRONT", None)
     try:
         rank_warm = [int(x) for x in g["rank_warm"]]
         rng = np.random.default_rng(99)
@@ -676,8 +682,10 @@ def test_recurrence_and_fused_front_equal_two_pass_form(built, name, steps):
             assert np.allclose(x, y, rtol=0, atol=1e-8 * max(np.abs(y).max(), 1e-300))
 
 
-@pytest.mark.parametrize("name,cw", [("rand120", "1"), ("maxcut100", None), ("coupled3x70", "1"), ("mix4", None), ("sdplp40", "1")])
-def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built, name, cw):
+@pytest.mark.parametrize("name,cw,nobatch", [("rand120", "1", False), ("maxcut100", None, False), ("coupled3x70", "1", False),
+                                             ("mix4", None, False), ("mix4", None, True), ("blk4x60", None, True),
+                                             ("sdplp40", "1", False)])
+def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built, name, cw, nobatch):
     """The start of a CG solve (k_cg_init) and the convergence test after an update (k_cg_check) normally ride on a
     neighbouring kernel (k_cw; k_cg_dir / k_refresh_w / k_average): every workgroup re-derives the scalars from the same
     partial sums in the same order, workgroup 0 publishes them.  LORADS_LAZY_SCALARS=0 launches them as the
@@ -686,6 +694,8 @@ def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built
     g = common.golden_trace(name) if name != "maxcut100" else None
     if cw:
         os.environ["LORADS_OP_CW"] = cw
+    if nobatch:  # cone-by-cone sweep: Max-Cut cones as stages > 0 (k_op_diag / k_cg_dir as carriers behind a gate)
+        os.environ["LORADS_NO_BATCH"] = "1"
     res = []
     try:
         for lazy in ("1", "0"):
@@ -728,10 +738,66 @@ def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built
                 s.close()
     finally:
         os.environ.pop("LORADS_OP_CW", None)
+        os.environ.pop("LORADS_NO_BATCH", None)
     (la, Ua, Va), (lb, Ub, Vb) = res
     assert la == lb, (la, lb)
     for x, y in zip(Ua + Va, Ub + Vb):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name,nobatch", [("maxcut100", False), ("mix4", True), ("blk4x60", True)])
+def test_fused_front_of_maxcut_cones_equals_the_separate_passes(built, name, nobatch):
+    """Max-Cut-type cones: right-hand side and initial residual of a solve come from one kernel (k_spmm2<FRONT> with the
+    row-local operator g_p (x_p . V_p) V_p in its epilogue) instead of k_spmm2 + k_op_diag.  Same arithmetic up to how
+    the compiler contracts the multiply-adds of the merged epilogue: against LORADS_SPLIT_FRONT=1 the sweeps must agree
+    to rounding -- same CG iteration counts, objectives to 1e-10, factors to 1e-9 of their scale."""
+    g = common.golden_trace(name) if name != "maxcut100" else None
+    if nobatch:
+        os.environ["LORADS_NO_BATCH"] = "1"
+    res = []
+    try:
+        for split in ("0", "1"):
+            os.environ["LORADS_SPLIT_FRONT"] = split
+            try:
+                s = common.hip_session(common.instance_path(name), phase1Tol=1e-2)
+            finally:
+                os.environ.pop("LORADS_SPLIT_FRONT", None)
+            try:
+                if g is not None:
+                    rank_warm = [int(x) for x in g["rank_warm"]]
+                    if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                        s.be.resize_rank(rank_warm)
+                    for k in range(s.nblk):
+                        n, r = s.block_shape(k)
+                        s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+                    s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+                    rho = float(g["admm_rho"][0])
+                    s.be.alm_to_admm()
+                else:  # the solver's own phase 1 and hand-over give the warm start and rho (as bench.py does)
+                    s.alm()
+                    s.alm_to_admm()
+                    res0 = s.results()
+                    rho = min(res0["admm_rho"] if res0["admm_rho"] > 0 else res0["alm_rho"], 5000.0)
+                s.be.init_constr(host.PAIR_UV)
+                log = []
+                for it, tol in enumerate([1e-8, 1e-6, 1e-13, 1e-7, 1e-5, 1e-10, 1e-9, 1e-12]):
+                    c, p, d, e = s.be.admm_step(rho, tol, 800)
+                    s.be.update_dual_var(rho)
+                    log.append((c, p, d, e))
+                res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)],
+                            [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)]))
+            finally:
+                s.close()
+    finally:
+        os.environ.pop("LORADS_NO_BATCH", None)
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    for it, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x[0] - y[0]) <= max(1, 0.01 * y[0]), (it, "cg iterations", x[0], y[0])
+        assert x[1] == pytest.approx(y[1], rel=1e-10, abs=1e-12), (it, "pObj", x[1], y[1])
+        assert x[2] == pytest.approx(y[2], rel=1e-10, abs=1e-12), (it, "dObj", x[2], y[2])
+        assert x[3] == pytest.approx(y[3], rel=1e-8, abs=1e-12), (it, "err1", x[3], y[3])
+    for x, y in zip(Ua + Va, Ub + Vb):
+        assert np.allclose(x, y, rtol=0, atol=1e-9 * max(np.abs(y).max(), 1e-300))
 
 
 def test_set_mat_invalidates_cached_pair_values(built):
