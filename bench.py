@@ -47,6 +47,33 @@ def traffic_from_profiles(workload):
     return d.get("cg_operator_application", {}).get("traffic_bytes"), os.path.relpath(best, ROOT)
 
 
+def rocprof_from_profiles(workload, op_kernels):
+    """Average duration (ms) of one CG operator application according to the committed rocprofv3 --kernel-trace --stats
+    summary of this same command (profiles/*_<workload>_kernel_stats.csv): sum over the operator's kernels of the
+    average of their most-called instantiation.  None if there is no such file."""
+    import csv
+    import re
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_%s_kernel_stats.csv" % workload):
+            best = os.path.join(pdir, f)
+    if not best:
+        return None, None
+    names = [k.split("<")[0] for k in re.findall(r"k_\w+(?:<CW>)?", op_kernels)]
+    names = ["k_spmm_ell" if k == "k_spmm" and "k_cw" in names else k for k in names]
+    tot = 0.0
+    with open(best) as fh:
+        rows = list(csv.DictReader(fh))
+    for k in names:
+        cand = [r for r in rows if re.search(r"\b%s\b" % k, r["Name"])]
+        if not cand:
+            return None, None
+        r = max(cand, key=lambda r: int(r["Calls"]))
+        tot += float(r["AverageNs"]) * 1e-6
+    return tot, os.path.relpath(best, ROOT)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -321,6 +348,13 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
                          "traffic": traffic_from_profiles(workload)[0],
                          "traffic_source": traffic_from_profiles(workload)[1]},
         }
+        # the committed rocprofv3 summary of this command, for comparison with the live event figure (events add a few
+        # microseconds of marker latency around a 5-25 us window)
+        pms, psrc = rocprof_from_profiles(workload, op_kernels)
+        if pms:
+            out["roofline"]["rocprofv3_avg_launch_ms"] = pms
+            out["roofline"]["rocprofv3_frac"] = b_mv / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["rocprofv3_source"] = psrc
         if world == 1 and with_cpu:
             try:
                 cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)

@@ -30,7 +30,10 @@
 //   k_cw         w_i straight from the factors, one wavefront per constraint (LORADSUVt + coneAUV)
 //   k_sval       S_e = [C_e] + sum_(i,a) weight_i a               (sdpDataWSum / addObjCoeff)
 //   k_sgram      S = G T                                          (coneAUV + sdpDataWSum fused)
-//   k_spmm       Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm); <CW>: S_e = a w_i
+//   k_spmm2      Y_p = epilogue(sum_(q,e) S_e X_q)  + fused dots  (mul_rk + axpy + dot/nrm), neighbour list read 8 slots
+//                per trip; <FRONT>: right-hand side AND initial residual of a CG solve from one gather of the rows
+//   k_spmm_ell   the operator's second half, slot coefficient a w_i, fixed-width slot list (k_spmm<CW>: CSR fallback)
+//   k_refresh_w  constraint bookkeeping after a solve when A(sym(U V^T)) has followed the CG updates (no gather pass)
 //   k_op_diag    fused operator when every A_i = a e_p e_p^T (Max-Cut): one pass
 //   k_op_entry   fused operator when every A_i holds one entry (matrix completion)
 //   k_dense_cx   W = C X for a dense objective on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
@@ -43,6 +46,8 @@
 // DIMACS) is enqueued on one stream WITHOUT host round trips, using the iteration counts of the
 // previous ADMM iteration as a speculation and device-side gates (struct Guard); the host
 // synchronises once per ADMM iteration and resumes a solve that needed more iterations.
+// The scalar steps of CGSolve (start of a solve, convergence test, restart bookkeeping) are not launches
+// of their own: they ride on the neighbouring kernel (structs InitArgs / Deferred / Carry below).
 //
 // Reductions: every reducing kernel writes one partial per workgroup; the consumer re-sums the
 // partials (<= 4096) in a fixed order, so results do not depend on scheduling.  Wave-level sums use

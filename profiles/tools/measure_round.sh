@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01f; mkdir -p $O
+O=gpurun_out/${1:-r01g}; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for w in rand20000 maxcut20000; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o p -- python3 bench.py --no-cpu --no-extra --workload $w --steps 50 --warmup 5 > $O/kt_$w.log 2>&1
