@@ -74,6 +74,35 @@ def rocprof_from_profiles(workload, op_kernels):
     return tot, os.path.relpath(best, ROOT)
 
 
+def pin_to_gpu_numa(torch, dev_index):
+    """One process per GPU, on the GPU's own socket: the host thread enqueues ~20 short kernels per ADMM iteration and
+    polls a word in pinned memory for the result, so launch doorbells and that poll are latency-bound; from the far
+    socket of the two-socket box a sharded ADMM iteration took 0.25 ms instead of 0.18 ms (profiles/tools/numa_probe.sh).
+    Restricts the calling thread to the CPUs sysfs lists as local to the device (LORADS_NO_PIN=1: leave it alone).
+    Returns the number of CPUs pinned to, 0 if nothing was done."""
+    if os.environ.get("LORADS_NO_PIN") == "1":
+        return 0
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/local_cpulist" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open(path) as fh:
+            txt = fh.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                lo, hi = part.split("-")
+                cpus.update(range(int(lo), int(hi) + 1))
+            elif part:
+                cpus.add(int(part))
+        target = cpus & os.sched_getaffinity(0)
+        if not target or len(target) == len(os.sched_getaffinity(0)):
+            return 0
+        os.sched_setaffinity(0, target)
+        return len(target)
+    except Exception:  # noqa: BLE001  (no sysfs, no such attribute, not permitted: run unpinned)
+        return 0
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -138,12 +167,20 @@ def make_allreduce(dist, torch, device, ext_stream=None):
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+    views = {}  # (address, count) -> tensor view of the library's buffer (the buffers live as long as the context)
+    if ext_stream is not None:
+        # the hook runs once per ADMM iteration between two kernel launches of the library: keep its host time small
+        # (no per-call stream context, no per-call tensor construction) -- the library's stream simply IS this
+        # process's current torch stream from here on
+        torch.cuda.set_stream(ext_stream)
+
     def fn(ptr, count, on_device):
         if on_device:
             if ext_stream is not None:
-                with torch.cuda.stream(ext_stream):
-                    t = torch.as_tensor(_Dev(ptr, count), device=device)
-                    dist.all_reduce(t)   # ordered after the kernels already on the stream; later kernels wait for it
+                t = views.get((ptr, count))
+                if t is None:
+                    t = views[(ptr, count)] = torch.as_tensor(_Dev(ptr, count), device=device)
+                dist.all_reduce(t)   # ordered after the kernels already on the stream; later kernels wait for it
             else:
                 t = torch.as_tensor(_Dev(ptr, count), device=device)
                 dist.all_reduce(t)
@@ -154,6 +191,41 @@ def make_allreduce(dist, torch, device, ext_stream=None):
             dist.all_reduce(t)
             a[:] = t.cpu().numpy()
     return fn
+
+
+def install_native_rccl(s, dist, torch, device, world, rank):
+    """Creates an RCCL communicator of our own (unique id from rank 0, shipped with torch.distributed) inside the RCCL
+    PyTorch has already loaded, and registers liblorads_rccl.so's C function as the library's all-reduce hook.  Every
+    rank learns whether ALL ranks succeeded (otherwise all fall back together).  Returns True on success."""
+    from lorads_amd import host as _h
+    lib = C.CDLL(os.path.join(_h.LIB_DIR, "liblorads_rccl.so"))
+    lib.lorads_rccl_last_error.restype = C.c_char_p
+    lib.lorads_rccl_comm_create.restype = C.c_void_p
+    lib.lorads_rccl_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    lib.lorads_rccl_comm_destroy.argtypes = [C.c_void_p]
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    ok = lib.lorads_rccl_open(path.encode() if os.path.exists(path) else b"") == 0
+    ident = C.create_string_buffer(128)
+    if ok and rank == 0:
+        ok = lib.lorads_rccl_unique_id(ident) == 0
+    box = [bytes(ident.raw) if (ok and rank == 0) else None]
+    dist.broadcast_object_list(box, src=0)
+    handle = None
+    if ok and box[0] is not None:
+        handle = lib.lorads_rccl_comm_create(box[0], rank, world, C.c_void_p(s.hip_stream()))
+    flag = torch.tensor([1.0 if handle else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize()
+    if flag.item() != 1.0:
+        if not handle:
+            log("rank %d: native RCCL hook: %s" % (rank, (lib.lorads_rccl_last_error() or b"").decode()))
+        else:
+            lib.lorads_rccl_comm_destroy(handle)
+        return False
+    s.set_allreduce_native(C.cast(lib.lorads_rccl_allreduce_hook, C.c_void_p), handle)
+    s.hip_allreduce_stream_ordered(1)
+    s._rccl_native = (lib, handle)  # destroyed with the session (bench.py: before s.close())
+    return True
 
 
 def install_allreduce(s, dist, torch, device, world, rank, backend):
@@ -171,6 +243,15 @@ def install_allreduce(s, dist, torch, device, world, rank, backend):
         return bool(ok.item() == 1.0)
 
     mode = "sync"
+    if backend == "nccl" and os.environ.get("LORADS_ALLREDUCE_SYNC", "0") != "1" and os.environ.get("LORADS_AR_TORCH") != "1":
+        # first choice: the native hook (liblorads_rccl.so): ncclAllReduce on the library's own stream, no Python and no
+        # second stream between two kernel launches of an ADMM iteration
+        try:
+            if install_native_rccl(s, dist, torch, device, world, rank) and check():
+                return "rccl-native"
+        except Exception as e:  # noqa: BLE001
+            log("rank %d: native RCCL hook unavailable: %s" % (rank, e))
+        log("rank %d: native RCCL hook not usable, trying torch.distributed in stream order" % rank)
     if backend == "nccl" and os.environ.get("LORADS_ALLREDUCE_SYNC", "0") != "1":
         try:
             ext = torch.cuda.ExternalStream(s.hip_stream(), device=device)
@@ -391,6 +472,16 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
         else:
             out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 0, "kind": "reference",
                                    "sample": "timed at N=1 only"}
+    if os.environ.get("LORADS_PRINT_CPU"):
+        with open("/proc/self/stat") as fh:
+            cpu_now = int(fh.read().rsplit(")", 1)[1].split()[36])
+        log("rank %d: cpu at end %d, affinity %d cpus" % (rank, cpu_now, len(os.sched_getaffinity(0))))
+    if dist:  # (the hook made the library's stream this process's current torch stream: hand torch its own back first)
+        torch.cuda.set_stream(torch.cuda.default_stream(device))
+    native = getattr(s, "_rccl_native", None)
+    if native:
+        s.hip_sync()
+        native[0].lorads_rccl_comm_destroy(native[1])
     s.close()
     return out
 
@@ -421,6 +512,8 @@ def main():
     dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    npin = pin_to_gpu_numa(torch, dev_index)
+    log("rank %d: cuda:%d, host thread pinned to %s" % (rank, dev_index, ("the GPU's %d local CPUs" % npin) if npin else "nothing (no NUMA information)"))
     if world > 1 or os.environ.get("LORADS_FORCE_DIST") == "1":  # (the knob measures the hook's own cost on one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")

@@ -424,7 +424,9 @@ struct lorads_hip_ctx {
     double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
     double *cr = nullptr, *cp = nullptr, *cQ = nullptr, *rhs = nullptr; // flat CG vectors
     double *Dtmp = nullptr;
-    double *cstage = nullptr; // m+2: [local constrValSum | objective part | miss flag] on its way through the all-reduce
+    double *cstage = nullptr; // m+2 (+ objective partials): [local constrValSum | objective part | miss flag | partials] on its way through the all-reduce
+    bool stage_clean = false; // cstage[0..m) is known to be zero (left so by k_commit_eval)
+    bool opt_ar_fast = true;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
     double *part = nullptr;   // NSLOT x MAXPART partial sums
     int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
@@ -511,7 +513,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
-        dalloc(&c->cstage, (size_t)c->m + 2) ||
+        dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) ||
         dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
         dalloc(&c->ring_ab, (size_t)2 * c->L)) {
@@ -525,6 +527,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0));
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
     c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
+    c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';

@@ -423,7 +423,13 @@ class Session:
                 return 1
         cb = ALLREDUCE_FN(_cb)
         self._keep.append(cb)
+        self.lib.lrd_session_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         _check(self.lib.lrd_session_set_allreduce(self.h, cb, None), "set_allreduce")
+
+    def set_allreduce_native(self, fn_ptr, user):
+        """a C function of type lorads_hip_allreduce_fn (address) and its user pointer: no Python in the hook"""
+        self.lib.lrd_session_set_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.lib.lrd_session_set_allreduce(self.h, fn_ptr, C.c_void_p(user)), "set_allreduce")
 
     def use_fused_step(self, on):
         self.lib.lrd_session_use_fused_step.argtypes = [C.c_void_p, C.c_int]

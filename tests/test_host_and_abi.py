@@ -25,6 +25,19 @@ def test_abi_library_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def test_rccl_hook_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "lorads_rccl.h")).read()
+    declared = sorted(set(re.findall(r"\b(lorads_rccl_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) == 6, declared
+    lib = C.CDLL(os.path.join(host.LIB_DIR, "liblorads_rccl.so"))
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    # no RCCL named and none on the default path that is not loadable -> an error code and a message, not a crash
+    lib.lorads_rccl_last_error.restype = C.c_char_p
+    if lib.lorads_rccl_open(b"/nonexistent/librccl.so") != 0:
+        assert b"dlopen" in lib.lorads_rccl_last_error()
+
+
 def test_host_library_exports_table_adaptor(built):
     lib = host.host_lib()
     for s in ("lrd_hip_backend_create", "lrd_read_sdpa", "lrd_alm_optimize", "lrd_admm_optimize", "lrd_solve", "lrd_reopt"):
