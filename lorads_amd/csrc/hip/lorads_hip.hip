@@ -186,16 +186,17 @@ struct Guard {
 // where the first predicated store needs the answer.  (`(skip && *skip) || (need && *need == 0)` at the top of a kernel
 // compiles to load - wait - branch - load - wait: two memory round trips before the kernel's first own load.)
 struct Gate { int vs, vn; };
+__device__ int g_gate_words[2] = {0, 1}; // what an absent gate reads: "do not skip", "satisfied"
 __device__ __forceinline__ Gate gate_load(const Guard &g) {
-    Gate t{0, 1};
-    if (g.skip || g.need) { // uniform: kernel arguments
-        const int *ps = g.skip ? g.skip : g.need, *pn = g.need ? g.need : g.skip;
-        t.vs = *ps;
-        t.vn = *pn;
-    }
+    // two UNCONDITIONAL loads (an absent gate reads the constant words): a load inside an `if` makes the compiler wait
+    // for it -- and for every load issued before it -- where the branches join
+    const int *ps = g.skip ? g.skip : &g_gate_words[0], *pn = g.need ? g.need : &g_gate_words[1];
+    Gate t;
+    t.vs = *ps;
+    t.vn = *pn;
     return t;
 }
-__device__ __forceinline__ bool gate_blocked(const Guard &g, const Gate &t) { return (g.skip && t.vs != 0) || (g.need && t.vn == 0); }
+__device__ __forceinline__ bool gate_blocked(const Guard &g, const Gate &t) { return t.vs != 0 || t.vn == 0; }
 #define GATE_OPEN (!gate_blocked(g, gt))
 __device__ __forceinline__ bool blocked(const Guard &g) { return gate_blocked(g, gate_load(g)); }
 // The gate words were written by the previous kernel, so reading them costs a cache-missing scalar load
