@@ -339,7 +339,7 @@ struct Pattern {              // one symmetric sparsity pattern with everything 
     double *e_val = nullptr;
     int *adj_ptr = nullptr, *adj_col = nullptr, *adj_e = nullptr; // row -> (neighbour, entry)
     double *S = nullptr;      // values on the pattern
-    double *S2 = nullptr;     // second image on the same pattern (fused front of a CG solve: sum_i w_i A_i); union pattern of k_cw cones only
+    double *S2 = nullptr;     // 2 ne doubles: {S_e, second image sum_i w_i A_i} side by side for the fused front of a CG solve (one 16-byte gather per slot); union pattern of k_cw cones only
     double *cbase = nullptr;  // C on the pattern (union pattern only)
     void release() {
         hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_val);
@@ -379,6 +379,7 @@ struct Block {
     double *ca_val = nullptr;                 // ... and its coefficient; all three padded to ca_ell per constraint when ca_ell > 0
     int ca_ell = 0;
     double *cadj_a = nullptr;
+    int cadj_ptr_host_n = 0;                  // number of slots in the CSR list (cadj_col / cadj_con / cadj_a)
     int cell_w = 0;                           // > 0: the slot list also in fixed width (8 or 16 per row) for k_spmm_ell
     int *cell_col = nullptr, *cell_con = nullptr;
     double *cell_a = nullptr;
@@ -1066,9 +1067,16 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
         if (!B.entry_only) return fail_msg("ubench: variants >= 100 need a single-entry cone");
         hipEvent_t e0, e1;
         HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+        if (which != 100 && which != 120 && which != 121) return fail_msg("ubench: unknown variant");
+        const Shape shp = shape_for(B.r);
         for (int it = -3; it < reps; ++it) {
             if (it == 0) HC(hipEventRecord(e0, c->stream));
-            op_entry(c, B, c->V + B.off, OP_CG, c->U + B.off, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
+            if (which == 100)
+                op_entry(c, B, c->V + B.off, OP_CG, c->U + B.off, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
+            else // 120 / 121: pure gathers of this cone's rows (the first na slots of its neighbour list: all row numbers < n)
+                SHAPE_DISPATCH(shp, LAUNCH((k_gather_probe<LG_, V2_, NS_>), nblocks_for((size_t)B.n, TPB / shp.lg), B.n, 16, B.pa.adj_col,
+                                           B.na, c->V + B.off, which == 121 ? c->U + B.off : (const double *)nullptr, B.r,
+                                           c->cQ + B.off));
         }
         HC(hipEventRecord(e1, c->stream));
         HC(hipEventSynchronize(e1));
@@ -1113,6 +1121,18 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             const int gv = 2048 >> (which - 6);
             LAUNCH(k_cg_update, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
                    (const double *)nullptr, 0, c->st_shadow);
+        } break;
+        case 20: case 21: case 22: case 23: case 24: {
+            // pure row gathers (every index is a row number < n: cadj_col holds neighbour rows; null = ascending rows)
+            // 20-22: 64 rows per 8-lane group, 40000 groups = 0.82 GB of 320-byte rows (deep queues, long kernel)
+            // 23-24: 16 rows per group, one group per row of the cone = the shape of the solve front (short kernel)
+            const bool shortk = which >= 23;
+            const int ngroups = shortk ? B.n : 40000, per = shortk ? 16 : 64;
+            const double *two = (which == 21 || which == 24) ? U : (const double *)nullptr; // rows of x and V in turn
+            const int *idx = which == 22 ? (const int *)nullptr : B.cadj_col;
+            const int nidx = which == 22 ? B.n : B.cadj_ptr_host_n;
+            if (nidx <= 0) return fail_msg("ubench: empty index list");
+            LAUNCH((k_gather_probe<8, true, 3>), nblocks_for((size_t)ngroups, TPB / 8), ngroups, per, idx, nidx, V, two, B.r, Q);
         } break;
         case 10: LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), 1024), B.nc, B.c_row, B.c_col, B.c_val, U, U,
                         B.r, part_slot(c, 4), NOGUARD); break;

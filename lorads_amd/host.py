@@ -370,7 +370,10 @@ class Session:
         """milliseconds of `reps` back-to-back launches of kernel variant `which` (diagnostic, see lorads_hip.h)"""
         lib, ctx = self._hip()
         ms = C.c_double()
-        _check(lib.lorads_hip_ubench(ctx, int(which), int(reps), C.byref(ms)), "ubench")
+        rc = lib.lorads_hip_ubench(ctx, int(which), int(reps), C.byref(ms))
+        if rc:
+            lib.lorads_hip_last_error.restype = C.c_char_p
+            raise RuntimeError("ubench: %s" % (lib.lorads_hip_last_error() or b"?").decode())
         return ms.value
 
     def hip_algorithmic_bytes(self, blk=0):

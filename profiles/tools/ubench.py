@@ -12,10 +12,15 @@ from lorads_amd import host  # noqa: E402
 NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>", 2: "k_spmm_ell (fixed-width slot list)",
          3: "k_spmm<CW> (CSR slot list)", 4: "k_spmm2<FRONT> (rhs + initial residual)", 5: "k_spmm2 (rhs only)",
          6: "k_cg_update 2048 wg", 7: "k_cg_update 1024 wg", 8: "k_cg_update 512 wg", 9: "k_cg_update 256 wg",
-         10: "k_obj", 11: "k_sval (two images)"}
+         10: "k_obj", 11: "k_sval (two images)",
+         20: "gather probe: 2.56 M random 320-B rows of V (6.4 MB table)", 21: "gather probe: rows of x and V in turn (12.8 MB)",
+         22: "gather probe: the same number of rows in ascending order",
+         23: "gather probe, front-shaped: 16 random rows of V per row, 20000 rows", 24: "gather probe, front-shaped, x and V in turn"}
+PROBE_BYTES = {20: 40000 * 64 * 320, 21: 40000 * 64 * 320, 22: 40000 * 64 * 320, 23: 20000 * 16 * 320, 24: 20000 * 16 * 320}
 
 
-ENTRY = {100: "k_op_entry (whole operator, single-entry constraints)"}
+ENTRY = {100: "k_op_entry (whole operator, single-entry constraints)",
+         120: "gather probe on this cone: 16 random rows of V per row", 121: "gather probe on this cone: rows of x and V in turn"}
 
 
 def main():
@@ -34,7 +39,12 @@ def main():
     s.be.init_constr(host.PAIR_UV)
     for w in which:
         ms = s.hip_ubench(w, reps)
-        print("%2d  %-45s %8.2f us/launch" % (w, NAMES[w], 1e3 * ms / reps), flush=True)
+        pb = dict(PROBE_BYTES)
+        if w in (120, 121):
+            n_, r_ = s.block_shape(0)
+            pb[w] = n_ * 16 * r_ * 8
+        extra = "  = %.2f TB/s of rows" % (pb[w] / (1e-3 * ms / reps) / 1e12) if w in pb else ""
+        print("%2d  %-45s %8.2f us/launch%s" % (w, NAMES[w], 1e3 * ms / reps, extra), flush=True)
     s.close()
 
 
