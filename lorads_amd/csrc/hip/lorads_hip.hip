@@ -436,6 +436,7 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
     bool final_pending = false;              // an evaluation's closing sums wait for the next hand-over (k_publish_final)
@@ -448,6 +449,10 @@ struct lorads_hip_ctx {
     Deferred pend_chk{};      // a convergence test waiting likewise (flushed as k_cg_check otherwise)
     Guard pend_chk_g{};
     bool opt_lazy_scalars = true; // LORADS_LAZY_SCALARS=0: every scalar step as its own launch
+    // a direction update (k_cg_dir) waiting for the row-local operator that follows it (k_op_diag forms the rows of p
+    // itself); sent off as its own launch if anything else comes first
+    struct PendDir { int kind = 0; CGState *st = nullptr; double *r = nullptr, *p = nullptr; size_t len = 0; int gv = 0;
+                     const double *rs_part = nullptr; int rs_np = 0; Guard g{}; } pend_dir;
     CGState *h_st = nullptr;  // pinned mirror
     double *h_scal = nullptr; // pinned mirror of scalars
     std::vector<Ring> ring;
@@ -530,6 +535,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
     c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
+    c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
