@@ -72,7 +72,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int MAXPART = 4096; // capacity of one partial-sum slot
-constexpr int NSLOT = 18;
+constexpr int NSLOT = 20; // (18, 19: start-of-solve and restart residual partials of the ADMM sweep, see solve_front)
 
 thread_local std::string g_err;
 int fail(const char *what, hipError_t e) {
@@ -452,7 +452,8 @@ struct lorads_hip_ctx {
     // a direction update (k_cg_dir) waiting for the row-local operator that follows it (k_op_diag forms the rows of p
     // itself); sent off as its own launch if anything else comes first
     struct PendDir { int kind = 0; CGState *st = nullptr; double *r = nullptr, *p = nullptr; size_t len = 0; int gv = 0;
-                     const double *rs_part = nullptr; int rs_np = 0; Guard g{}; } pend_dir;
+                     const double *rs_part = nullptr; int rs_np = 0; Guard g{}; bool seg = false; int half = 0; } pend_dir;
+    int *seg_tile_cone = nullptr;             // row tile (workgroup of a row kernel) -> cone, merged cone
     CGState *h_st = nullptr;  // pinned mirror
     double *h_scal = nullptr; // pinned mirror of scalars
     std::vector<Ring> ring;
@@ -576,7 +577,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);

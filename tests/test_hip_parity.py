@@ -745,6 +745,42 @@ def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built
         assert np.array_equal(x, y)
 
 
+def test_carried_scalar_steps_on_a_grid_larger_than_the_device(built):
+    """A carried scalar step sums partials at the top of its carrier; the carrier writes its own partials at its end.
+    With more workgroups than the device holds at once (Max-Cut n = 20000, r = 40: 625 resident of 625; n = 48000: 1500
+    workgroups) late workgroups start after early ones have finished, so the two sets of partials must never share a
+    slot -- they once did (start of a solve / restart residual vs the operator's p.Q partials), which showed up as a
+    one-in-eight flake on a two-workgroup cone.  Bit-for-bit against the separate launches at n = 48000."""
+    path = os.path.join("/tmp", "lorads_test_maxcut48000.dat-s")
+    if not os.path.exists(path):
+        from lorads_amd import instances
+        instances.write_sdpa(instances.maxcut(48000, 200000, 48001), path)
+    res = []
+    for lazy in ("1", "0"):
+        os.environ["LORADS_LAZY_SCALARS"] = lazy
+        try:
+            s = common.hip_session(path, timesLogRank=3.7, phase1Tol=1e-1)
+        finally:
+            os.environ.pop("LORADS_LAZY_SCALARS", None)
+        try:
+            s.alm()
+            s.alm_to_admm()
+            res0 = s.results()
+            rho = min(res0["admm_rho"] if res0["admm_rho"] > 0 else res0["alm_rho"], 5000.0)
+            s.be.init_constr(host.PAIR_UV)
+            log = []
+            for tol in (1e-6, 1e-9, 1e-4, 1e-12):
+                c, p, d, e = s.be.admm_step(rho, tol, 200)
+                s.be.update_dual_var(rho)
+                log.append((c, p, d, e))
+            res.append((log, s.be.get_mat(host.MAT_U, 0)))
+        finally:
+            s.close()
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert max(c for c, _, _, _ in res[0][0]) > 2
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("name,nobatch", [("maxcut100", False), ("mix4", True), ("blk4x60", True)])
 def test_fused_front_of_maxcut_cones_equals_the_separate_passes(built, name, nobatch):
     """Max-Cut-type cones: right-hand side and initial residual of a solve come from one kernel (k_spmm2<FRONT> with the
