@@ -436,6 +436,15 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
             out["roofline"]["rocprofv3_avg_launch_ms"] = pms
             out["roofline"]["rocprofv3_frac"] = b_mv / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["rocprofv3_source"] = psrc
+        if op_kernels == "k_op_diag":
+            # Max-Cut-type cones: from iteration 1 on the operator kernel also forms the direction p = r + beta p of that
+            # iteration (reads r and p, writes p: 3 more factor passes), so its launches move more than the operator's
+            # algorithmic bytes; priced here for the launches that carry it (most of them)
+            fused = b_mv + 3.0 * 8.0 * info["n"] * info["rank"]
+            out["roofline"]["with_fused_direction_update"] = {
+                "bytes_per_launch": fused,
+                "frac_events": fused / (mv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prof["sampled"] else None,
+                "frac_rocprofv3": (fused / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pms else None}
         if world == 1 and with_cpu:
             try:
                 cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)
