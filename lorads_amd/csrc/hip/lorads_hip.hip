@@ -730,7 +730,7 @@ static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
         c->ls_np = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
         LAUNCH(k_cv_rd, c->ls_np, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.T, B.cv, B.row_idx, c->q12, c->q12 + m, c->b, c->csum,
                c->lambda, part_slot(c, 10));
-        const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 1024);
+        const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
         SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4),
                                   part_slot(c, 6)));
         if (defer_p12) *defer_p12 = go; // the caller's line-search kernel sums the partials (same order, same values)
@@ -1141,8 +1141,9 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             if (nidx <= 0) return fail_msg("ubench: empty index list");
             LAUNCH((k_gather_probe<8, true, 3>), nblocks_for((size_t)ngroups, TPB / 8), ngroups, per, idx, nidx, V, two, B.r, Q);
         } break;
-        case 10: LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), 1024), B.nc, B.c_row, B.c_col, B.c_val, U, U,
-                        B.r, part_slot(c, 4), NOGUARD); break;
+        case 10: case 13: case 14: // k_obj on at most 1024 / 2048 / 4096 workgroups
+            LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), which == 10 ? 1024 : which == 13 ? 2048 : 4096), B.nc,
+                   B.c_row, B.c_col, B.c_val, U, U, B.r, part_slot(c, 4), NOGUARD); break;
         case 11: LAUNCH(k_sval, std::max(1, nblocks_for((size_t)B.pu.ne, TPB)), B.pu.ne, B.pu.e_ptr, B.pu.e_con, B.pu.e_val, B.pu.cbase,
                         (int)W_COMPACT, WArgs{B.w_op, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0}, B.pu.S, NOGUARD,
                         (CGState *)nullptr, 0, (const double *)B.w_op, B.pu.S2); break;
