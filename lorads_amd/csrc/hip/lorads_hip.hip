@@ -64,6 +64,7 @@
 #include <mutex>
 #include <thread>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "lorads_hip.h"
@@ -1126,7 +1127,7 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
                        (double *)nullptr, NOGUARD, (const double *)nullptr); break;
         case 6: case 7: case 8: case 9: { // k_cg_update with 2048 / 1024 / 512 / 256 workgroups (alpha = 0 / 1: arrays stay put)
             const int gv = 2048 >> (which - 6);
-            LAUNCH(k_cg_update, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
+            LAUNCH(k_cg_update<true>, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
                    (const double *)nullptr, 0, c->st_shadow);
         } break;
         case 20: case 21: case 22: case 23: case 24: {
