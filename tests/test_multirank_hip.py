@@ -86,3 +86,18 @@ def test_two_ranks_on_device_match_single_process(built, name, params, world):
     e = gold[-1]  # the reference's own run of the same file (possibly at a tighter phase2Tol): converged objective
     gap = abs(e["pObj"] - e["dObj"]) / (1 + abs(e["pObj"]) + abs(e["dObj"]))
     assert abs(a["pObj"] - e["pObj"]) <= max(2e-5, 10 * gap) * (1 + abs(e["pObj"]))
+
+
+@pytest.mark.timeout(300)
+def test_native_rccl_hook_whole_solves_on_one_rank(built):
+    """liblorads_rccl.so (ncclAllReduce in stream order on the library's stream, RCCL bound with dlopen) as the all-reduce
+    hook of whole solves on an RCCL communicator of size 1 (the box has one GPU): every call site of the hook -- device
+    buffers of the ADMM evaluation and of phase 1, host buffers of the rank agreement -- against the same solves
+    without a hook.  Runs as a child process (it initialises torch.distributed with the nccl backend)."""
+    import subprocess
+    tool = os.path.join(ROOT, "profiles", "tools", "native_hook_solve.py")
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=280, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if " rccl-native " in ln or " MISMATCH " in ln or " stream-ordered " in ln or " sync " in ln]
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert len(lines) == 4 and all(" rccl-native ok " in ln for ln in lines), lines
