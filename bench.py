@@ -505,7 +505,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Max-Cut n=20000 companion run")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--sample-every", type=int, default=4)
+    ap.add_argument("--sample-every", type=int, default=8, help="time every n-th operator application with HIP events")
     a = ap.parse_args()
 
     import torch
