@@ -335,16 +335,19 @@ int upload(T **p, const std::vector<T> &v) {
 
 struct Pattern {              // one symmetric sparsity pattern with everything the kernels need
     int ne = 0;               // unique lower-tri entries
+    int nslot = 0;            // adjacency slots
     int *erow = nullptr, *ecol = nullptr;
     int *e_ptr = nullptr, *e_con = nullptr; // entry -> (local constraint, value)
     double *e_val = nullptr;
     int *adj_ptr = nullptr, *adj_col = nullptr, *adj_e = nullptr; // row -> (neighbour, entry)
+    int *adj_dyn = nullptr;    // per slot: the entry if some constraint touches it (its coefficient changes: gathered from S), else -1
+    double *adj_sval = nullptr; // per slot: the coefficient of an entry no constraint touches (C on the pattern; streamed with the list)
     double *S = nullptr;      // values on the pattern
     double *S2 = nullptr;     // 2 ne doubles: {S_e, second image sum_i w_i A_i} side by side for the fused front of a CG solve (one 16-byte gather per slot); union pattern of k_cw cones only
     double *cbase = nullptr;  // C on the pattern (union pattern only)
     void release() {
         hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_val);
-        hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(S); hipFree(S2); hipFree(cbase);
+        hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(adj_dyn); hipFree(adj_sval); hipFree(S); hipFree(S2); hipFree(cbase);
     }
 };
 
@@ -951,6 +954,7 @@ int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
         Block &B = *bp;
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
+        if (B.pu.nslot) LAUNCH(k_scale, grid1d((size_t)B.pu.nslot), (size_t)B.pu.nslot, s, B.pu.adj_sval); // (the list's own copy of C)
         if (B.dense_c) LAUNCH(k_scale, grid1d((size_t)B.npad * B.npad), (size_t)B.npad * B.npad, s, B.Cfull);
         if (B.is_lp && B.n) LAUNCH(k_scale, grid1d((size_t)B.n), (size_t)B.n, s, B.lp_cobj);
     }
@@ -1119,10 +1123,10 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             break;
         case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
                        (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
-        case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, (const double *)B.pu.S2, V,
+        case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)B.pu.S2, V,
                        B.r, 0, U, (const double *)nullptr, 1.0, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD,
                        (const double *)nullptr); break;
-        case 5: LAUNCH((k_spmm2<8, true, 3, false>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, (const double *)nullptr, V,
+        case 5: LAUNCH((k_spmm2<8, true, 3, false>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)nullptr, V,
                        B.r, (int)OP_RHS, (const double *)nullptr, (const double *)nullptr, 1.0, rhs, (double *)nullptr, part_slot(c, 1),
                        (double *)nullptr, NOGUARD, (const double *)nullptr); break;
         case 6: case 7: case 8: case 9: { // k_cg_update with 2048 / 1024 / 512 / 256 workgroups (alpha = 0 / 1: arrays stay put)
@@ -1142,6 +1146,10 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             if (nidx <= 0) return fail_msg("ubench: empty index list");
             LAUNCH((k_gather_probe<8, true, 3>), nblocks_for((size_t)ngroups, TPB / 8), ngroups, per, idx, nidx, V, two, B.r, Q);
         } break;
+        case 25: LAUNCH((k_gather_probe2<8, true, 3, 0>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
+        case 26: LAUNCH((k_gather_probe2<8, true, 3, 1>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
+        case 27: LAUNCH((k_gather_probe2<8, true, 3, 3>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
+        case 28: LAUNCH((k_gather_probe2<8, true, 3, 7>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
         case 10: case 13: case 14: // k_obj on at most 1024 / 2048 / 4096 workgroups
             LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), which == 10 ? 1024 : which == 13 ? 2048 : 4096), B.nc,
                    B.c_row, B.c_col, B.c_val, U, U, B.r, part_slot(c, 4), NOGUARD); break;

@@ -15,7 +15,9 @@ NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>",
          10: "k_obj", 11: "k_sval (two images)", 13: "k_obj, up to 2048 workgroups", 14: "k_obj, up to 4096 workgroups",
          20: "gather probe: 2.56 M random 320-B rows of V (6.4 MB table)", 21: "gather probe: rows of x and V in turn (12.8 MB)",
          22: "gather probe: the same number of rows in ascending order",
-         23: "gather probe, front-shaped: 16 random rows of V per row, 20000 rows", 24: "gather probe, front-shaped, x and V in turn"}
+         23: "gather probe, front-shaped: 16 random rows of V per row, 20000 rows", 24: "gather probe, front-shaped, x and V in turn",
+         25: "front-shaped probe on the union neighbour list, 16 slots per row", 26: "  + the rows' real lists (5-35 slots)",
+         27: "  + a coefficient gather per slot", 28: "  + own row read, full row written (= k_spmm2 without epilogue)"}
 PROBE_BYTES = {20: 40000 * 64 * 320, 21: 40000 * 64 * 320, 22: 40000 * 64 * 320, 23: 20000 * 16 * 320, 24: 20000 * 16 * 320}
 
 
