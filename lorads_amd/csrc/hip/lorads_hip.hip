@@ -355,6 +355,7 @@ struct Block {
     int n = 0, r = 0, nrow = 0, na = 0, nc = 0;
     size_t off = 0;           // offset of this cone in the flat factor arrays
     int *row_idx = nullptr;
+    bool row_idx_identity = false; // row_idx[i] == i for every local constraint (a cone that sees all constraints in order)
     int *a_ptr = nullptr, *a_e = nullptr;  // constraint CSR over the A-pattern
     double *a_val = nullptr;
     Pattern pa, pu;
@@ -638,7 +639,7 @@ static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
     for (Block *bp : cones) {
         Block &B = *bp;
         WArgs wa{};
-        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
+        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
         if (B.dense_c) dense_cx(c, B, c->R + B.off, B.Wd, NOGUARD);
         int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), NOGUARD,
@@ -843,7 +844,7 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         c->ls_np = 0;
         LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum);
         WArgs wa{};
-        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx; wa.rho = rho;
+        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
         const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
         LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
