@@ -1112,9 +1112,9 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
         if (it == 0) HC(hipEventRecord(e0, c->stream));
         switch (which) {
         case 0: LAUNCH((k_cw<8, true, 3>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op, (double *)nullptr,
-                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}); break;
+                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{}); break;
         case 1: LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
-                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}); break;
+                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{}); break;
         case 2:
             if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
                                       B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q,
