@@ -311,7 +311,7 @@ __device__ __forceinline__ int run_init(const InitArgs &ia, const Guard &g, doub
     return conv ? 2 : 0;
 }
 
-enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3 };
+enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3, W_ADMM_V = 4 };
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
 enum { CHK_ITER = 1, CHK_RESTART = 2 };
 enum { DIR_BETA = 1, DIR_RESTART = 2 };
@@ -441,6 +441,7 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
