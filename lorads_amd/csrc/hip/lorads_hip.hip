@@ -336,8 +336,10 @@ int upload(T **p, const std::vector<T> &v) {
 struct Pattern {              // one symmetric sparsity pattern with everything the kernels need
     int ne = 0;               // unique lower-tri entries
     int nslot = 0;            // adjacency slots
+    int n_owned = 0;          // constraints that have an owner pair in e_con_own
     int *erow = nullptr, *ecol = nullptr;
     int *e_ptr = nullptr, *e_con = nullptr; // entry -> (local constraint, value)
+    int *e_con_own = nullptr; // e_con with the sign bit set on ONE pair per constraint (its "owner": k_sval with a dual update on board); null if some constraint has no entry
     double *e_val = nullptr;
     int *adj_ptr = nullptr, *adj_col = nullptr, *adj_e = nullptr; // row -> (neighbour, entry)
     int *adj_dyn = nullptr;    // per slot: the entry if some constraint touches it (its coefficient changes: gathered from S), else -1
@@ -346,7 +348,7 @@ struct Pattern {              // one symmetric sparsity pattern with everything 
     double *S2 = nullptr;     // 2 ne doubles: {S_e, second image sum_i w_i A_i} side by side for the fused front of a CG solve (one 16-byte gather per slot); union pattern of k_cw cones only
     double *cbase = nullptr;  // C on the pattern (union pattern only)
     void release() {
-        hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_val);
+        hipFree(erow); hipFree(ecol); hipFree(e_ptr); hipFree(e_con); hipFree(e_con_own); hipFree(e_val);
         hipFree(adj_ptr); hipFree(adj_col); hipFree(adj_e); hipFree(adj_dyn); hipFree(adj_sval); hipFree(S); hipFree(S2); hipFree(cbase);
     }
 };
@@ -441,6 +443,12 @@ struct lorads_hip_ctx {
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
     unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
     bool use_publish = true;
+    // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
+    // from the updated multipliers and stores them to lambda_alt, then the two vectors swap); sent off as k_dual_update
+    // by flush_pending if anything else comes first
+    bool pend_dual = false;
+    double pend_dual_rho = 0.0;
+    double *lambda_alt = nullptr;
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
@@ -526,7 +534,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
         fprintf(stderr, "lorads_hip: %d cone(s), merged view %s\n", c->nb, c->has_merged ? "on" : (c->merged_ok ? "off (ranks differ)" : "not applicable"));
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
-    if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
+    if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->lambda_alt, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
         dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) ||
         dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
@@ -583,7 +591,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
@@ -594,6 +602,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_sync(lorads_hip_ctx *c) {
+    flush_pending(c);
     HC(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -917,6 +926,12 @@ int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxi
 
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
     c->ls_np = 0;
+    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && !c->ar) { // (see pend_dual)
+        flush_pending(c);
+        c->pend_dual = true;
+        c->pend_dual_rho = rho;
+        return 0;
+    }
     LAUNCH(k_dual_update, nblocks_for((size_t)c->m, TPB), c->m, rho, c->b, c->csum, c->lambda);
     return 0;
 }
@@ -934,6 +949,7 @@ static void invalidate_t(lorads_hip_ctx *c) {
 }
 
 int lorads_hip_alm_to_admm(lorads_hip_ctx *c) {
+    flush_pending(c);
     invalidate_t(c);
     HC(hipMemcpyAsync(c->V, c->R, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
     HC(hipMemcpyAsync(c->U, c->V, sizeof(double) * c->all_elem, hipMemcpyDeviceToDevice, c->stream));
@@ -965,6 +981,7 @@ int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
 }
 
 int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double *cm) {
+    flush_pending(c);
     double *base = mat_base(c, which);
     if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
     Block &B = c->blk[k];
@@ -979,6 +996,7 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
 }
 
 int lorads_hip_get_mat(lorads_hip_ctx *c, int32_t which, int32_t k, double *cm) {
+    flush_pending(c);
     double *base = mat_base(c, which);
     if (!base || k < 0 || k >= c->nb) return fail_msg("get_mat: bad argument");
     Block &B = c->blk[k];
@@ -991,6 +1009,7 @@ int lorads_hip_get_mat(lorads_hip_ctx *c, int32_t which, int32_t k, double *cm) 
 }
 
 int lorads_hip_set_vec(lorads_hip_ctx *c, int32_t which, const double *v) {
+    flush_pending(c);
     c->ls_np = 0;
     double *d = vec_base(c, which);
     if (!d) return fail_msg("set_vec: bad argument");
@@ -1000,6 +1019,7 @@ int lorads_hip_set_vec(lorads_hip_ctx *c, int32_t which, const double *v) {
 }
 
 int lorads_hip_get_vec(lorads_hip_ctx *c, int32_t which, double *v) {
+    flush_pending(c);
     double *d = vec_base(c, which);
     if (!d) return fail_msg("get_vec: bad argument");
     HC(hipMemcpyAsync(v, d, sizeof(double) * (size_t)c->m, hipMemcpyDeviceToHost, c->stream));
@@ -1008,6 +1028,7 @@ int lorads_hip_get_vec(lorads_hip_ctx *c, int32_t which, double *v) {
 }
 
 int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
+    flush_pending(c);
     // AUG_RANK (data/lorads_solver.c:806-906): keep the old columns, new columns = 1/sqrt(k) on their
     // leading diagonal (lpRandomDiag :776-786), clear L-BFGS history and CG workspaces
     std::vector<std::vector<double>> keep[4];
@@ -1044,6 +1065,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
 }
 
 int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
+    flush_pending(c);
     HC(hipStreamSynchronize(c->stream));
     drain_events(c);
     c->prof = enable;
@@ -1058,6 +1080,7 @@ int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
 }
 
 int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
+    flush_pending(c);
     HC(hipStreamSynchronize(c->stream));
     drain_events(c);
     s[0] = (double)c->n_matvec;
