@@ -210,9 +210,15 @@ def install_native_rccl(s, dist, torch, device, world, rank):
         ok = lib.lorads_rccl_unique_id(ident) == 0
     box = [bytes(ident.raw) if (ok and rank == 0) else None]
     dist.broadcast_object_list(box, src=0)
-    handle = None
-    if ok and box[0] is not None:
-        handle = lib.lorads_rccl_comm_create(box[0], rank, world, C.c_void_p(s.hip_stream()))
+    # the communicator is created collectively: a rank that cannot take part (library or symbol missing) must be known to
+    # all BEFORE anybody enters ncclCommInitRank, or the others would wait for it for ever
+    ready = torch.tensor([1.0 if (ok and box[0] is not None) else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+    if ready.item() != 1.0:
+        if not ok:
+            log("rank %d: native RCCL hook: %s" % (rank, (lib.lorads_rccl_last_error() or b"").decode()))
+        return False
+    handle = lib.lorads_rccl_comm_create(box[0], rank, world, C.c_void_p(s.hip_stream()))
     flag = torch.tensor([1.0 if handle else 0.0], dtype=torch.float64, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     torch.cuda.synchronize()
