@@ -781,23 +781,28 @@ def test_carried_scalar_steps_on_a_grid_larger_than_the_device(built):
     assert np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("name,nobatch", [("maxcut100", False), ("mix4", True), ("blk4x60", True)])
-def test_fused_front_of_maxcut_cones_equals_the_separate_passes(built, name, nobatch):
+@pytest.mark.parametrize("name,nobatch,knob", [("maxcut100", False, "LORADS_SPLIT_FRONT"), ("mix4", True, "LORADS_SPLIT_FRONT"),
+                                               ("blk4x60", True, "LORADS_SPLIT_FRONT"), ("maxcut100", False, "LORADS_EXACT_REFRESH"),
+                                               ("blk4x60", True, "LORADS_EXACT_REFRESH"), ("mix4", True, "LORADS_EXACT_REFRESH")])
+def test_fused_front_of_maxcut_cones_equals_the_separate_passes(built, name, nobatch, knob):
     """Max-Cut-type cones: right-hand side and initial residual of a solve come from one kernel (k_spmm2<FRONT> with the
     row-local operator g_p (x_p . V_p) V_p in its epilogue) instead of k_spmm2 + k_op_diag.  Same arithmetic up to how
     the compiler contracts the multiply-adds of the merged epilogue: against LORADS_SPLIT_FRONT=1 the sweeps must agree
-    to rounding -- same CG iteration counts, objectives to 1e-10, factors to 1e-9 of their scale."""
+    to rounding -- same CG iteration counts, objectives to 1e-10, factors to 1e-9 of their scale.
+    knob = LORADS_EXACT_REFRESH: the same comparison for the constraint refresh of Max-Cut cones, which is made of row dots
+    U_p . V_p that every front leaves exact and the CG updates keep current (k_op_diag's p_p . V_p), against the full
+    refresh (k_pairdots + k_cv) after every solve."""
     g = common.golden_trace(name) if name != "maxcut100" else None
     if nobatch:
         os.environ["LORADS_NO_BATCH"] = "1"
     res = []
     try:
         for split in ("0", "1"):
-            os.environ["LORADS_SPLIT_FRONT"] = split
+            os.environ[knob] = split
             try:
                 s = common.hip_session(common.instance_path(name), phase1Tol=1e-2)
             finally:
-                os.environ.pop("LORADS_SPLIT_FRONT", None)
+                os.environ.pop(knob, None)
             try:
                 if g is not None:
                     rank_warm = [int(x) for x in g["rank_warm"]]
