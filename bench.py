@@ -60,8 +60,7 @@ def rocprof_from_profiles(workload, op_kernels):
             best = os.path.join(pdir, f)
     if not best:
         return None, None
-    names = [k.split("<")[0] for k in re.findall(r"k_\w+(?:<CW>)?", op_kernels)]
-    names = ["k_spmm_ell" if k == "k_spmm" and "k_cw" in names else k for k in names]
+    names = re.findall(r"k_\w+", op_kernels)
     tot = 0.0
     with open(best) as fh:
         rows = list(csv.DictReader(fh))

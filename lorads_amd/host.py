@@ -395,7 +395,7 @@ class Session:
         lib, ctx = self._hip()
         k = C.c_int()
         _check(lib.lorads_hip_operator_kind(ctx, blk, C.byref(k)), "operator_kind")
-        return ["k_pairdots+k_sgram+k_spmm", "k_pairdots+k_cv+k_sval+k_spmm", "k_op_diag", "k_op_entry", "k_cw+k_spmm<CW>"][k.value]
+        return ["k_pairdots+k_sgram+k_spmm2", "k_pairdots+k_cv+k_sval+k_spmm2", "k_op_diag", "k_op_entry", "k_cw+k_spmm_ell"][k.value]
 
     def hip_stream(self):
         """hipStream_t of the library as an integer (torch.cuda.ExternalStream takes it)"""

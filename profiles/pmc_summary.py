@@ -51,7 +51,7 @@ elif "k_cw" in ks and "k_spmm_ell" in ks:
     if "k_spmm2" in ks:  # front of a solve (right-hand side + initial residual in one pass)
         out["solve_front"] = {"kernels": ["k_spmm2"], "traffic_bytes": ks["k_spmm2"]["read_bytes_median"] + ks["k_spmm2"]["write_bytes_mean"]}
 elif "k_cw" in ks and "k_spmm" in ks:
-    # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm<CW> (the more frequent k_spmm
+    # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm<CW> CSR form (the more frequent k_spmm
     # population -> median)
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_cw", "k_spmm"))
     out["cg_operator_application"] = {"kernels": ["k_cw", "k_spmm"], "traffic_bytes": op}

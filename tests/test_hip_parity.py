@@ -508,7 +508,7 @@ def test_constraint_wise_operator_vs_reference_golden(built, name):
         s = common.hip_session(common.instance_path(name))
         try:
             kinds = {s.hip_operator_kind(k) for k in range(s.nblk)}
-            assert "k_cw+k_spmm<CW>" in kinds, kinds
+            assert "k_cw+k_spmm_ell" in kinds, kinds
             log = common.replay_trace(s, g, rtol=1e-9, resync=True)
             assert len(log) > 50
         finally:
@@ -599,7 +599,7 @@ def test_operator_variants_agree_fullsize(built):
         finally:
             os.environ.pop("LORADS_OP_CW", None)
         try:
-            assert s.hip_operator_kind(0) == ("k_cw+k_spmm<CW>" if cw == "1" else "k_pairdots+k_sgram+k_spmm")
+            assert s.hip_operator_kind(0) == ("k_cw+k_spmm_ell" if cw == "1" else "k_pairdots+k_sgram+k_spmm2")
             be = s.be
             be.set_mat(host.MAT_R, 0, R0)
             be.set_vec(host.VEC_LAMBDA, lam0)
@@ -643,7 +643,7 @@ def test_recurrence_and_fused_front_equal_two_pass_form(built, name, steps):
                 os.environ.pop("LORADS_EXACT_REFRESH", None)
                 os.environ.pop("LORADS_SPLIT_FRONT", None)
             try:
-                assert "k_cw+k_spmm<CW>" in {s.hip_operator_kind(k) for k in range(s.nblk)}
+                assert "k_cw+k_spmm_ell" in {s.hip_operator_kind(k) for k in range(s.nblk)}
                 rank_warm = [int(x) for x in g["rank_warm"]]
                 if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
                     s.be.resize_rank(rank_warm)
