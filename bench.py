@@ -197,16 +197,23 @@ def install_native_rccl(s, dist, torch, device, world, rank):
     PyTorch has already loaded, and registers liblorads_rccl.so's C function as the library's all-reduce hook.  Every
     rank learns whether ALL ranks succeeded (otherwise all fall back together).  Returns True on success."""
     from lorads_amd import host as _h
-    lib = C.CDLL(os.path.join(_h.LIB_DIR, "liblorads_rccl.so"))
-    lib.lorads_rccl_last_error.restype = C.c_char_p
-    lib.lorads_rccl_comm_create.restype = C.c_void_p
-    lib.lorads_rccl_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
-    lib.lorads_rccl_comm_destroy.argtypes = [C.c_void_p]
-    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-    ok = lib.lorads_rccl_open(path.encode() if os.path.exists(path) else b"") == 0
+    # loading and binding happen INSIDE the agreed section: a rank that fails here reports ok = False through the MIN
+    # all-reduce below instead of raising while the others are already in a collective
+    lib, ok = None, False
     ident = C.create_string_buffer(128)
-    if ok and rank == 0:
-        ok = lib.lorads_rccl_unique_id(ident) == 0
+    try:
+        lib = C.CDLL(os.path.join(_h.LIB_DIR, "liblorads_rccl.so"))
+        lib.lorads_rccl_last_error.restype = C.c_char_p
+        lib.lorads_rccl_comm_create.restype = C.c_void_p
+        lib.lorads_rccl_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        lib.lorads_rccl_comm_destroy.argtypes = [C.c_void_p]
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        ok = lib.lorads_rccl_open(path.encode() if os.path.exists(path) else b"") == 0
+        if ok and rank == 0:
+            ok = lib.lorads_rccl_unique_id(ident) == 0
+    except Exception as e:  # noqa: BLE001
+        log("rank %d: native RCCL hook: %s" % (rank, e))
+        ok = False
     box = [bytes(ident.raw) if (ok and rank == 0) else None]
     dist.broadcast_object_list(box, src=0)
     # the communicator is created collectively: a rank that cannot take part (library or symbol missing) must be known to
@@ -214,10 +221,14 @@ def install_native_rccl(s, dist, torch, device, world, rank):
     ready = torch.tensor([1.0 if (ok and box[0] is not None) else 0.0], dtype=torch.float64, device=device)
     dist.all_reduce(ready, op=dist.ReduceOp.MIN)
     if ready.item() != 1.0:
-        if not ok:
+        if not ok and lib is not None:
             log("rank %d: native RCCL hook: %s" % (rank, (lib.lorads_rccl_last_error() or b"").decode()))
         return False
-    handle = lib.lorads_rccl_comm_create(box[0], rank, world, C.c_void_p(s.hip_stream()))
+    try:
+        handle = lib.lorads_rccl_comm_create(box[0], rank, world, C.c_void_p(s.hip_stream()))
+    except Exception as e:  # noqa: BLE001
+        log("rank %d: native RCCL hook: %s" % (rank, e))
+        handle = None
     flag = torch.tensor([1.0 if handle else 0.0], dtype=torch.float64, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     torch.cuda.synchronize()
@@ -235,50 +246,70 @@ def install_native_rccl(s, dist, torch, device, world, rank):
 
 def install_allreduce(s, dist, torch, device, world, rank, backend):
     """Registers the hook; uses the stream-ordered form with RCCL after a self-check through the library
-    (constrValSum filled with rank+1 must come back as world*(world+1)/2), else the synchronising form."""
+    (constrValSum filled with rank+1 must come back as world*(world+1)/2), else the synchronising form.
+    Returns (mode, ranks_seen): ranks_seen = the N that solves N(N+1)/2 = what the library's own hook returned, so a
+    run that silently has fewer ranks than --gpus cannot pass as N."""
     from lorads_amd import host as _h
     want = world * (world + 1) / 2.0
+    seen = [0]
 
     def check():
-        s.be.set_vec(_h.VEC_CONSTR_SUM, np.full(s.m, rank + 1.0))
+        s.be.set_vec(_h.VEC_CONSTR_SUM, np.full(max(s.m, 1), rank + 1.0)[:s.m])
         s.hip_selfcheck_allreduce()
         got = s.be.get_vec(_h.VEC_CONSTR_SUM)
+        g0 = float(got[0]) if len(got) else want
+        seen[0] = int(round((np.sqrt(8.0 * g0 + 1.0) - 1.0) / 2.0))
         ok = torch.tensor([1.0 if np.all(got == want) else 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         return bool(ok.item() == 1.0)
+
+    def drop_native():
+        native = getattr(s, "_rccl_native", None)
+        if native:
+            s.hip_sync()
+            native[0].lorads_rccl_comm_destroy(native[1])
+            s._rccl_native = None
 
     mode = "sync"
     if backend == "nccl" and os.environ.get("LORADS_ALLREDUCE_SYNC", "0") != "1" and os.environ.get("LORADS_AR_TORCH") != "1":
         # first choice: the native hook (liblorads_rccl.so): ncclAllReduce on the library's own stream, no Python and no
         # second stream between two kernel launches of an ADMM iteration
-        try:
-            if install_native_rccl(s, dist, torch, device, world, rank) and check():
-                return "rccl-native"
-        except Exception as e:  # noqa: BLE001
-            log("rank %d: native RCCL hook unavailable: %s" % (rank, e))
+        if install_native_rccl(s, dist, torch, device, world, rank) and check():
+            return "rccl-native", seen[0]
+        drop_native()
         log("rank %d: native RCCL hook not usable, trying torch.distributed in stream order" % rank)
     if backend == "nccl" and os.environ.get("LORADS_ALLREDUCE_SYNC", "0") != "1":
         try:
             ext = torch.cuda.ExternalStream(s.hip_stream(), device=device)
             s.set_allreduce(make_allreduce(dist, torch, device, ext))
             s.hip_allreduce_stream_ordered(1)
-            if check():
-                mode = "stream-ordered"
+            okl = 1.0
         except Exception as e:  # noqa: BLE001
             log("stream-ordered all-reduce unavailable: %s" % e)
+            okl = 0.0
+        t = torch.tensor([okl], dtype=torch.float64, device=device)   # all ranks take the same branch
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if t.item() == 1.0 and check():
+            mode = "stream-ordered"
     if mode == "sync":
         s.hip_allreduce_stream_ordered(0)
         s.set_allreduce(make_allreduce(dist, torch, device, None))
         if not check():
             raise RuntimeError("all-reduce hook self-check failed")
-    return mode
+    return mode, seen[0]
 
 
-def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
+def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0):
     """Times the CPU path on the host cores, rank 0 / N = 1 only: the compiled reference
-    (oracle/_ref, kind "reference") when it is present, else the plain-C restatement (kind "port")."""
-    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    (oracle/_ref, kind "reference") when it is present, else the plain-C restatement (kind "port").
+    A cone with n^2 > 2^31 (cfg5) overflows the packed index of the reference's default 32-bit build
+    (io/lorads_file_io.c:281): there the 64-bit build of the same sources (oracle/Makefile ref64: lorads_int = int64_t,
+    MKL's ILP64 interface layer) is the one that can read the file."""
+    wide = n_max * n_max > 2**31 - 1
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver64" if wide else "ref_driver")
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    if wide:
+        env["MKL_INTERFACE_LAYER"] = "ILP64"
     if os.path.exists(drv):
         try:
             its = 2
@@ -303,7 +334,8 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
                     "check": {"iterations": its, "cg_iters": int(kv["cg_iters"]), "pObj": float(kv["pObj"]),
                               "dObj": float(kv["dObj"]), "err1": float(kv["err1"])},
                     "sample": "%d ADMM iterations (%s CG iterations) of the same workload from the same start state, "
-                              "compiled reference (MKL sequential, 1 thread) on the host" % (its, kv["cg_iters"])}
+                              "compiled reference%s (MKL sequential, 1 thread) on the host"
+                              % (its, kv["cg_iters"], ", 64-bit lorads_int build" if wide else "")}
         except Exception as e:  # noqa: BLE001
             log_fn("reference baseline unavailable (%s); timing the C restatement" % e)
     from lorads_amd import host
@@ -311,13 +343,13 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
     s = common.oracle_session(path, timesLogRank=tlr)
     try:
         raw = np.fromfile(state_file, dtype=np.float64)
-        n, r = s.block_shape(0)
-        U = raw[:n * r].reshape(r, n).T
-        V = raw[n * r:2 * n * r].reshape(r, n).T
-        lam = raw[2 * n * r:2 * n * r + s.m]
-        s.be.set_mat(host.MAT_U, 0, U)
-        s.be.set_mat(host.MAT_V, 0, V)
-        s.be.set_vec(host.VEC_LAMBDA, lam)
+        o = 0
+        for k in range(s.nblk):
+            n, r = s.block_shape(k)
+            s.be.set_mat(host.MAT_U, k, raw[o:o + n * r].reshape(r, n).T)
+            s.be.set_mat(host.MAT_V, k, raw[o + n * r:o + 2 * n * r].reshape(r, n).T)
+            o += 2 * n * r
+        s.be.set_vec(host.VEC_LAMBDA, raw[o:o + s.m])
         s.be.init_constr(host.PAIR_UV)
         s.be.cal_obj(host.PAIR_UV)
         err1 = s.be.update_dimacs(host.PAIR_UV)
@@ -335,28 +367,55 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn):
                       "plain-C restatement (oracle/) on 1 host core" % (its, cg)}
 
 
-def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
+def hip_source_hash():
+    """sha256 over the HIP sources the kernels are built from (what a committed profile must have been taken from)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lorads_amd", "csrc", "hip")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".cpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def profile_stamp_ok(relpath):
+    """A committed profile file may be replayed into the JSON line only if the stamp written next to it when it was
+    collected (profiles/<round>_stamp.json: hash of the HIP sources, git head) matches the sources of THIS run."""
+    rnd = os.path.basename(relpath).split("_")[0]
+    stamp = os.path.join(ROOT, "profiles", "%s_stamp.json" % rnd)
+    if not os.path.exists(stamp):
+        return False, None
+    with open(stamp) as fh:
+        st = json.load(fh)
+    return st.get("hip_source_sha256") == hip_source_hash(), st.get("git_head")
+
+
+def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, tlr=None):
+    tlr = a.times_log_rank if tlr is None else tlr
+    strong = a.scaling == "strong"
     base = build_instance(workload, "/tmp/lorads_bench_%s.dat-s" % workload) if rank == 0 else None
     if dist:
         dist.barrier()
     base = "/tmp/lorads_bench_%s.dat-s" % workload
     path = base
-    if world > 1:
+    if world > 1 and not strong:
         path = "/tmp/lorads_bench_%s_x%d.dat-s" % (workload, world)
         if rank == 0:
             replicate_blocks(base, world, path)
         dist.barrier()
 
     s = host.Session.open(path)
-    s.set_params(verbose=0, timesLogRank=a.times_log_rank, phase1Tol=1e-2, reoptLevel=0)
-    s.prepare(world, rank)
+    s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+    s.prepare(world, rank)   # cones dealt round-robin over the ranks
     s.attach_hip()
-    ar_mode = None
+    ar_mode, ranks_seen = None, 1
     if dist:
-        ar_mode = install_allreduce(s, dist, torch, device, world, rank, os.environ.get("LORADS_DIST_BACKEND", "nccl"))
-        log("rank %d: all-reduce hook mode: %s" % (rank, ar_mode))
+        ar_mode, ranks_seen = install_allreduce(s, dist, torch, device, world, rank, os.environ.get("LORADS_DIST_BACKEND", "nccl"))
+        log("rank %d: all-reduce hook mode: %s, ranks seen through the library's hook: %d" % (rank, ar_mode, ranks_seen))
     be = s.be
     info = s.block_info(0)
+    nloc = s.nblk
     # ---- untimed set-up: phase 1 on the GPU gives the factors, then the hand-off
     t0 = time.time()
     s.alm()
@@ -366,18 +425,17 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
     be.init_constr(host.PAIR_UV)
     be.cal_obj(host.PAIR_UV)
     err1 = be.update_dimacs(host.PAIR_UV)
-    log("rank %d: phase 1 took %.2fs (%d inner its), rho=%.4g err1=%.3e n=%d r=%d" %
-        (rank, time.time() - t0, int(res["alm_inner"]), rho, err1, info["n"], info["rank"]))
+    log("rank %d: phase 1 took %.2fs (%d inner its), rho=%.4g err1=%.3e, %d local cone(s), n=%d r=%d" %
+        (rank, time.time() - t0, int(res["alm_inner"]), rho, err1, nloc, info["n"], info["rank"]))
     state_file = "/tmp/lorads_bench_state_%d.bin" % os.getpid()
     if rank == 0 and world == 1 and with_cpu:
-        U, V = be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0)
+        UV0 = [(be.get_mat(host.MAT_U, k), be.get_mat(host.MAT_V, k)) for k in range(nloc)]
         lam0 = be.get_vec(host.VEC_LAMBDA)
         with open(state_file, "wb") as f:
-            f.write(np.asfortranarray(U).tobytes(order="F"))
-            f.write(np.asfortranarray(V).tobytes(order="F"))
+            for U, V in UV0:
+                f.write(np.asfortranarray(U).tobytes(order="F"))
+                f.write(np.asfortranarray(V).tobytes(order="F"))
             f.write(lam0.tobytes())
-        err1_start = err1
-        U0, V0 = U.copy(), V.copy()
 
     # ---- warm-up, then exactly K timed steps
     err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup, s)
@@ -394,6 +452,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = s.hip_profile_read()
+    samples_timed = s.hip_profile_samples()
     s.hip_profile(0, 1)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -402,57 +461,134 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
         c = torch.tensor([float(cg_iters)], dtype=torch.float64, device=device)
         dist.all_reduce(c)
         cg_iters = int(c.item())
-    b_mv, b_cg = s.hip_algorithmic_bytes(0)
+    # ---- further windows of K steps each (outside the contract's timed region): spread of ms_per_step
+    win_ms = [1e3 * elapsed / a.steps]
+    for _ in range(max(0, a.windows - 1)):
+        if dist:
+            dist.barrier()
+        s.hip_sync()
+        tw = time.perf_counter()
+        err1, _, _, _ = admm_steps(be, host, rho, err1, a.steps, s)
+        s.hip_sync()
+        if dist:
+            dist.barrier()
+        w = time.perf_counter() - tw
+        if dist:
+            t = torch.tensor([w], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        win_ms.append(1e3 * w / a.steps)
+    # ---- untimed roofline pass: EVERY operator application between two HIP events until enough samples exist, then the
+    # live operator back to back with nothing riding along (ubench variant 200: boundaries included, no event latency)
+    roof_samples, alone_ms = [], None
+    if a.roofline_samples > 0:
+        per_step = prof["matvec_launches"] / max(a.steps, 1)
+        if dist:   # every rank must run the same number of (collective-carrying) iterations
+            t = torch.tensor([per_step], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            per_step = float(t.item())
+        per_step = max(per_step, 0.25)
+        todo = int(min(4000, np.ceil(a.roofline_samples / per_step))) + 2
+        chunk = int(max(1, min(todo, 600 // max(1.0, 1.5 * prof["matvec_launches"] / max(a.steps, 1)))))  # (event pool: 1024 samples)
+        s.hip_profile(1, 1)
+        while todo > 0:
+            err1, _, _, _ = admm_steps(be, host, rho, err1, min(chunk, todo), s)
+            roof_samples = s.hip_profile_samples()   # (drains the event pool)
+            todo -= chunk
+        s.hip_profile(0, 1)
+        try:
+            reps = 200
+            alone_ms = s.hip_ubench(200, reps) / reps
+        except Exception as e:  # noqa: BLE001
+            log("rank %d: back-to-back operator run unavailable: %s" % (rank, e))
+    b_mv = b_cg = 0.0
+    for k in range(nloc):
+        x, y = s.hip_algorithmic_bytes(k)
+        b_mv += x
+        b_cg += y
     op_kernels = s.hip_operator_kind(0)
     out = None
     if rank == 0:
-        mv_ms = prof["sampled_ms"] / prof["sampled"] if prof["sampled"] else float("nan")
-        achieved = b_mv / (mv_ms * 1e-3) / 1e9 if prof["sampled"] else None
+        # weak: N blocks, every ADMM iteration of the N-block problem advances N blocks -> block-iterations / s (equal to
+        # iterations / s at N = 1); strong: ONE problem -> iterations / s
+        units = a.steps if strong else world * a.steps
+        med = lambda v: float(np.median(v)) if len(v) else None  # noqa: E731
+        mv_ms = med(roof_samples) if roof_samples else (prof["sampled_ms"] / prof["sampled"] if prof["sampled"] else float("nan"))
+        achieved = b_mv / (mv_ms * 1e-3) / 1e9 if mv_ms == mv_ms and mv_ms else None
+        cfg_txt = ("%s: %d cone(s) of n=%d r=%d dealt over %d GPU(s) (%d on rank 0)" % (workload, s.nblk_global, info["n"], info["rank"], world, nloc)
+                   if strong else
+                   "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
+                   % (workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]))
         out = {
-            "metric": "ADMM iters/sec (+ inner CG-iters/sec), single-block n=20000 r=40",
-            "value": world * a.steps / elapsed,
-            "unit": "ADMM iters/s",
+            "metric": "ADMM iters/sec (+ inner CG-iters/sec), single-block n=20000 r=40" if workload == "rand20000"
+                      else "ADMM iters/sec (+ inner CG-iters/sec), %s" % workload,
+            "value": units / elapsed,
+            "unit": "ADMM iters/s" if (strong or world == 1) else "ADMM block-iters/s (N blocks x iterations / s)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_windows": win_ms, "ms_per_step_median": med(win_ms),
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "ranks_seen": ranks_seen,
+            "admm_iters_per_s_of_the_sharded_problem": a.steps / elapsed,
             "cg_iters_per_s": cg_iters / elapsed,
-            "cg_iters_per_admm_iter": cg_iters / (world * a.steps),
-            "config": {"workload": "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
-                                   % (workload, world, info["n"], info["rank"], info["nrow"], info["na"], info["nc"]),
-                       "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": world,
-                       "parallelism": ("block-per-GPU, 1 all-reduce of the shared m-vector per ADMM iteration (%s)" % ar_mode) if world > 1 else "single GPU",
-                       "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (a.times_log_rank, rho)},
+            "cg_iters_per_admm_iter": cg_iters / units,
+            "config": {"workload": cfg_txt,
+                       "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": s.nblk_global,
+                       "parallelism": ("%s, 1 all-reduce of the shared m-vector per ADMM iteration (%s)"
+                                       % ("cones dealt over the ranks" if strong else "block-per-GPU", ar_mode)) if world > 1 else "single GPU",
+                       "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (tlr, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
             "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x): %s" % op_kernels,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "algorithmic_bytes_per_launch": b_mv, "avg_launch_ms": mv_ms,
-                         "launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"]),
+                         "how": "median over %d operator applications, each between two HIP events on the library's stream, "
+                                "untimed pass after the timed region (events add ~1-3 us of marker latency per sample)" % len(roof_samples),
+                         "launches_timed": len(roof_samples),
+                         "event_ms_mean": float(np.mean(roof_samples)) if roof_samples else None,
+                         "event_ms_median": med(roof_samples),
+                         "event_ms_p10_p90": [float(np.percentile(roof_samples, 10)), float(np.percentile(roof_samples, 90))] if roof_samples else None,
+                         "in_timed_region": {"launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"]),
+                                             "event_ms_mean": (prof["sampled_ms"] / prof["sampled"]) if prof["sampled"] else None,
+                                             "event_ms_median": med(samples_timed)},
+                         "operator_alone_back_to_back": None if alone_ms is None else {
+                             "avg_ms": alone_ms, "frac": b_mv / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "what": "200 applications of the live operator back to back between ONE event pair, no scalar "
+                                     "step riding along (kernel boundaries included, no per-sample event latency)"},
                          "cg_iter_bytes": b_cg,
                          "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
-                         "traffic": traffic_from_profiles(workload)[0],
-                         "traffic_source": traffic_from_profiles(workload)[1]},
+                         "traffic": None},
         }
-        # the committed rocprofv3 summary of this command, for comparison with the live event figure (events add a few
-        # microseconds of marker latency around a 5-25 us window)
+        # committed rocprofv3 / PMC summaries of this same command: replayed ONLY when their stamp matches the HIP sources
+        # of this run (a profile of older kernels is not this run's evidence)
+        tr, tsrc = traffic_from_profiles(workload)
         pms, psrc = rocprof_from_profiles(workload, op_kernels)
-        if pms:
-            out["roofline"]["rocprofv3_avg_launch_ms"] = pms
-            out["roofline"]["rocprofv3_frac"] = b_mv / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            out["roofline"]["rocprofv3_source"] = psrc
+        for val, src, key in ((tr, tsrc, "traffic"), (pms, psrc, "rocprofv3")):
+            if val is None:
+                continue
+            ok, head = profile_stamp_ok(src)
+            if not ok:
+                out["roofline"][key + "_source"] = "%s is stale (HIP sources changed since it was collected): not replayed" % src
+                continue
+            if key == "traffic":
+                out["roofline"]["traffic"] = val
+                out["roofline"]["traffic_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
+            else:
+                out["roofline"]["rocprofv3_avg_launch_ms"] = val
+                out["roofline"]["rocprofv3_frac"] = b_mv / (val * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out["roofline"]["rocprofv3_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
         if op_kernels == "k_op_diag":
             # Max-Cut-type cones: from iteration 1 on the operator kernel also forms the direction p = r + beta p of that
             # iteration (reads r and p, writes p: 3 more factor passes), so its launches move more than the operator's
             # algorithmic bytes; priced here for the launches that carry it (most of them)
-            fused = b_mv + 3.0 * 8.0 * info["n"] * info["rank"]
+            fused = b_mv + 3.0 * 8.0 * info["n"] * info["rank"] * nloc
             out["roofline"]["with_fused_direction_update"] = {
                 "bytes_per_launch": fused,
-                "frac_events": fused / (mv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if prof["sampled"] else None,
-                "frac_rocprofv3": (fused / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pms else None}
+                "frac_events": fused / (mv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if achieved else None}
         if world == 1 and with_cpu:
             try:
-                cb = cpu_baseline(path, a.times_log_rank, rho, state_file, a.cpu_budget, log)
+                cb = cpu_baseline(path, tlr, rho, state_file, a.cpu_budget, log, n_max=info["n"])
                 cb["host_cores_total"] = os.cpu_count()
                 try:
                     with open("/proc/cpuinfo") as fh:
@@ -465,8 +601,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
                 if chk:
                     # parity at the full size: the device path replays the same number of ADMM iterations from the very
                     # state the reference started from (same rho, same tolerance rule) and must stand where it stands
-                    be.set_mat(host.MAT_U, 0, U0)
-                    be.set_mat(host.MAT_V, 0, V0)
+                    for k, (U, V) in enumerate(UV0):
+                        be.set_mat(host.MAT_U, k, U)
+                        be.set_mat(host.MAT_V, k, V)
                     be.set_vec(host.VEC_LAMBDA, lam0)
                     be.init_constr(host.PAIR_UV)
                     be.cal_obj(host.PAIR_UV)
@@ -496,8 +633,43 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu):
     if native:
         s.hip_sync()
         native[0].lorads_rccl_comm_destroy(native[1])
+        s._rccl_native = None
     s.close()
     return out
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: this process -- which has made NO GPU call and has not even
+    imported torch -- starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run
+    would export), waits for them, forwards rank 0's JSON line and fails if any child fails.  Children are separate
+    processes (subprocess, no exec from a process that touched the GPU)."""
+    import socket
+    import __graft_entry__
+    __graft_entry__.build()   # once, before the ranks start (they only load the built libraries)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rk in range(a.gpus):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LORADS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for pr in procs[1:]:
+        try:
+            rcs.append(pr.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:   # rank 0 is gone and this one is still in a collective: end exactly it
+            pr.kill()
+            rcs.append(pr.wait())
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(rcs) or not line:
+        log("bench.py: ranks exited with codes %s%s" % (rcs, "" if line else "; no JSON line from rank 0"))
+        sys.exit(1)
+    print(line[-1], flush=True)
 
 
 def main():
@@ -505,13 +677,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="rand20000", help="rand20000 (headline, cfg3b) | maxcut20000 (cfg3a) | any NAMED")
-    ap.add_argument("--times-log-rank", type=float, default=4.0)
+    ap.add_argument("--workload", default=None, help="rand20000 (headline, cfg3b; default) | maxcut20000 (cfg3a) | "
+                    "matcomp50000 (cfg5) | blk16x4000 (cfg4; default of --scaling strong) | any NAMED instance")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: N copies of the block, one per GPU (value = N x iterations / s); strong: the cones of ONE "
+                         "problem (blk16x4000: 16 cones, BASELINE cfg4) dealt over the N ranks (value = iterations / s)")
+    ap.add_argument("--times-log-rank", type=float, default=None)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Max-Cut n=20000 companion run")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--sample-every", type=int, default=8, help="time every n-th operator application with HIP events")
+    ap.add_argument("--windows", type=int, default=5, help="after the timed region: this many further windows of --steps "
+                    "steps (reported as ms_per_step_windows / _median; the headline value is the FIRST window)")
+    ap.add_argument("--roofline-samples", type=int, default=200, help="untimed pass after the timed region: every operator "
+                    "application timed with HIP events until this many samples exist")
     a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "blk16x4000" if a.scaling == "strong" else "rand20000"
+    if a.times_log_rank is None:
+        a.times_log_rank = {"matcomp50000": 5.5, "blk16x4000": 2.0}.get(a.workload, 4.0)
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a, sys.argv[1:])
 
     import torch
     import __graft_entry__
@@ -545,11 +732,10 @@ def main():
     out = run_workload(a, a.workload, torch, dist, device, world, rank, host, not a.no_cpu)
     if rank == 0 and world == 1 and a.workload == "rand20000" and not a.no_extra:
         # the north-star target sentence is phrased on Max-Cut n = 20000, r = 40 (cfg3a): reported beside the headline
-        ex = run_workload(a, "maxcut20000", torch, dist, device, world, rank, host, not a.no_cpu)
-        out["extra"] = [{k: ex[k] for k in ("value", "unit", "ms_per_step", "cg_iters_per_s", "cg_iters_per_admm_iter", "config",
-                                              "roofline", "cpu_baseline", "state") if k in ex}]
-        if "speedup_vs_cpu_1core" in ex:
-            out["extra"][0]["speedup_vs_cpu_1core"] = ex["speedup_vs_cpu_1core"]
+        keys = ("value", "unit", "ms_per_step", "ms_per_step_median", "cg_iters_per_s", "cg_iters_per_admm_iter", "config", "roofline",
+                "cpu_baseline", "state", "parity_full_size", "speedup_vs_cpu_1core")
+        ex = run_workload(a, "maxcut20000", torch, dist, device, world, rank, host, not a.no_cpu, tlr=4.0)
+        out["extra"] = [{k: ex[k] for k in keys if k in ex}]
     if dist:
         dist.barrier()
         dist.destroy_process_group()

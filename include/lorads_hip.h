@@ -148,20 +148,6 @@ int lorads_hip_set_allreduce_stream_ordered(lorads_hip_ctx *ctx, int32_t on);
 /* all-reduces constrValSum through the hook once (lets the caller validate its hook) */
 int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *ctx);
 
-/* measurement hooks (bench.py): HIP-event timing of the dominant kernels on the library's stream.
- * stats[0..7] = {cg_matvec launches, speculation misses (resumed solves), cg iterations, cg solves,
- *                sampled matvec launches, sampled matvec ms, spmm sampled launches, spmm sampled ms} */
-int lorads_hip_profile(lorads_hip_ctx *ctx, int32_t enable, int32_t sample_every);
-int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);
-/* Diagnostic (profiles/tools/ubench.py): `reps` back-to-back launches of kernel variant `which` on cone 0, elapsed
- * milliseconds of all of them.  Overwrites the CG scratch vectors; the factors are left alone. */
-int lorads_hip_ubench(lorads_hip_ctx *ctx, int32_t which, int32_t reps, double *ms);
-/* algorithmic bytes of one CG operator application / one CG iteration of block blk */
-int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes_matvec, double *bytes_cg_iter);
-/* which kernels apply the CG operator of block blk: 0 = k_pairdots + k_sgram + k_spmm (Gram of the A_i),
- * 1 = k_pairdots + k_cv + k_sval + k_spmm, 2 = k_op_diag (every A_i one diagonal entry), 3 = k_op_entry (every A_i
- * one entry), 4 = k_cw + k_spmm<CW> (constraint values straight from the factors, slot coefficients a w_i) */
-int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
 int lorads_hip_sync(lorads_hip_ctx *ctx);
 
 #ifdef __cplusplus

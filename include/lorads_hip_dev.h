@@ -1,0 +1,38 @@
+/* lorads_hip_dev.h -- measurement and diagnostic entries of liblorads_hip.so (bench.py, profiles/tools/).
+ *
+ * NOT part of the drop-in surface: nothing here replaces a reference function, and a reference-side shim
+ * (integration/lorads_func_hip.c) never includes this header.  The product ABI is lorads_hip.h.
+ */
+#ifndef LORADS_HIP_DEV_H
+#define LORADS_HIP_DEV_H
+
+#include "lorads_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP-event timing of the CG operator application on the library's stream.
+ * stats[0..7] = {cg_matvec launches, speculation misses (resumed solves), cg iterations, cg solves,
+ *                sampled matvec launches, sampled matvec ms, spmm sampled launches, spmm sampled ms} */
+int lorads_hip_profile(lorads_hip_ctx *ctx, int32_t enable, int32_t sample_every);
+int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);
+/* the individual samples (milliseconds per timed operator application) behind stats[4..5], oldest first: copies
+ * min(cap, count) of them to out and returns the count in *n (for a median / spread next to the mean) */
+int lorads_hip_profile_samples(lorads_hip_ctx *ctx, double *out, int32_t cap, int32_t *n);
+/* Diagnostic (profiles/tools/ubench.py): `reps` back-to-back launches of kernel variant `which` on cone 0, elapsed
+ * milliseconds of all of them.  Overwrites the CG scratch vectors; the factors are left alone.
+ * which = 200: the live CG operator of cone 0 (whatever kernels apply it), applied to the CG direction buffer, no
+ * scalar step riding along -- "the operator alone", boundaries between consecutive launches included. */
+int lorads_hip_ubench(lorads_hip_ctx *ctx, int32_t which, int32_t reps, double *ms);
+/* algorithmic bytes of one CG operator application / one CG iteration of block blk */
+int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes_matvec, double *bytes_cg_iter);
+/* which kernels apply the CG operator of block blk: 0 = k_pairdots + k_sgram + k_spmm (Gram of the A_i),
+ * 1 = k_pairdots + k_cv + k_sval + k_spmm, 2 = k_op_diag (every A_i one diagonal entry), 3 = k_op_entry (every A_i
+ * one entry), 4 = k_cw + k_spmm_ell (constraint values straight from the factors, slot coefficients a w_i) */
+int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -55,6 +55,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -68,6 +69,7 @@
 #include <vector>
 
 #include "lorads_hip.h"
+#include "lorads_hip_dev.h"
 
 namespace {
 
@@ -483,6 +485,7 @@ struct lorads_hip_ctx {
     long n_sweeps = 0;        // ADMM sweeps run so far (cadence of the exact constraint refresh, see constr_by_recurrence)
     long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
     double ms_samp = 0, ms_samp_spmm = 0;
+    std::vector<float> samp_ms; // every timed operator application of the current profiling window
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pend_mv, pend_sp;
     std::vector<hipEvent_t> ev_pool; // pre-created (hipEventCreate is too slow for the timed region)
     size_t ev_next = 0;
@@ -1078,6 +1081,16 @@ int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
     }
     c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = c->n_resume = 0;
     c->ms_samp = c->ms_samp_spmm = 0;
+    c->samp_ms.clear();
+    return 0;
+}
+
+int lorads_hip_profile_samples(lorads_hip_ctx *c, double *out, int32_t cap, int32_t *n) {
+    flush_pending(c);
+    HC(hipStreamSynchronize(c->stream));
+    drain_events(c);
+    *n = (int32_t)c->samp_ms.size();
+    for (int32_t i = 0; i < cap && i < *n; ++i) out[i] = c->samp_ms[(size_t)i];
     return 0;
 }
 
@@ -1102,6 +1115,30 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
 int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms) {
     if (c->nb < 1) return fail_msg("ubench: no cone");
     Block &B = c->blk[0];
+    if (which == 200) { // the live operator of cone 0, back to back, nothing riding along
+        flush_pending(c);
+        hipEvent_t e0, e1;
+        HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+        const int prof0 = c->prof;
+        c->prof = 0;
+        HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
+        hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
+        const bool tv = B.t_uv_valid;
+        for (int it = -3; it < reps; ++it) {
+            if (it == 0) HC(hipEventRecord(e0, c->stream));
+            apply_operator(c, B, c->V + B.off, c->cp + B.off, OP_CG, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
+        }
+        HC(hipEventRecord(e1, c->stream));
+        HC(hipEventSynchronize(e1));
+        float f = 0;
+        HC(hipEventElapsedTime(&f, e0, e1));
+        *ms = f;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        c->prof = prof0;
+        c->n_matvec -= reps + 3;
+        B.t_uv_valid = (B.use_cw || B.diag_only || B.entry_only) ? tv : false; // (those write w_op only; the others overwrite the pair dots)
+        return 0;
+    }
     if (which >= 100) { // single-entry cones (matrix completion): the whole-operator kernels, any rank
         if (!B.entry_only) return fail_msg("ubench: variants >= 100 need a single-entry cone");
         hipEvent_t e0, e1;

@@ -188,6 +188,8 @@ typedef struct {
     double t_alm, t_admm;
     int admm_iters_first, cg_iters_first;
     int use_fused_step; /* 1: use lrd_backend.admm_step when the table has it */
+    int be_fail;        /* a table slot returned non-zero (device error, refused resize, failed all-reduce): the loops
+                         * stop with LRD_RET_NUM_ERR instead of steering on numbers nobody produced */
 } lrd_solver;
 
 /* ---- params / problem ---- */

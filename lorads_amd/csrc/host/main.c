@@ -28,11 +28,16 @@ int main(int argc, char **argv) {
     }
     lrd_session *s = lrd_session_open(argv[1]);
     if (!s) return 1;
-    for (int i = 2; i + 1 < argc; i += 2)
+    for (int i = 2; i < argc; i += 2) {
+        if (i + 1 >= argc) {
+            fprintf(stderr, "option %s lacks a value\n", argv[i]);
+            return 2;
+        }
         if (strncmp(argv[i], "--", 2) || lrd_session_set_param(s, argv[i] + 2, argv[i + 1])) {
             fprintf(stderr, "unknown option %s\n", argv[i]);
             return 2;
         }
+    }
     lrd_session_prepare(s, 1, 0);
     char self[4096], lib[4200];
     ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
@@ -45,7 +50,12 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (lrd_session_attach(s, &be)) return 1;
-    lrd_session_solve(s);
+    const int rc = lrd_session_solve(s);
+    if (rc != 0) {
+        fprintf(stderr, "lorads: the solve failed (code %d): a backend call reported an error\n", rc);
+        lrd_session_close(s);
+        return 3;
+    }
     double r[16], r2[4];
     lrd_session_results(s, r);
     lrd_session_results2(s, r2);

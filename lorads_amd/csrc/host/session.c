@@ -150,11 +150,11 @@ int lrd_session_admm_steps(lrd_session *s, int steps, double rho, double io[4]) 
             int c = 0;
             if (be->admm_update_var(be->ctx, rho, tol, 800, &c)) return 1;
             cg += c;
-            be->cal_obj(be->ctx, LRD_PAIR_UV, &pobj);
-            be->cal_dual_obj(be->ctx, &dobj);
-            be->update_dimacs(be->ctx, LRD_PAIR_UV, &err1);
+            if (be->cal_obj(be->ctx, LRD_PAIR_UV, &pobj) || be->cal_dual_obj(be->ctx, &dobj) ||
+                be->update_dimacs(be->ctx, LRD_PAIR_UV, &err1))
+                return 1;
         }
-        be->update_dual_var(be->ctx, rho);
+        if (be->update_dual_var(be->ctx, rho)) return 1;
     }
     io[0] = err1; io[1] = (double)cg; io[2] = pobj; io[3] = dobj;
     return 0;

@@ -20,6 +20,10 @@
 
 #define LMIN(a, b) ((a) < (b) ? (a) : (b))
 #define LMAX(a, b) ((a) > (b) ? (a) : (b))
+/* every table slot returns 0 / non-zero (lorads_hip.h); the reference's kernels return void and cannot fail, ours can
+ * (device error, rank refused, all-reduce hook failed).  A failure is remembered in the solver and the loops below leave
+ * with LRD_RET_NUM_ERR at their next check. */
+#define BE(call) do { if ((call) != 0) s->be_fail = 1; } while (0)
 
 double lrd_time(void) {
     struct timeval tv;
@@ -131,6 +135,15 @@ void lrd_solver_clear(lrd_solver *s) {
     s->rank = NULL;
 }
 
+/* "time is up?" -- with sharded cones every rank must take the same branch, or the ones that stay enter the next
+ * collective alone and wait for ever: the clocks are the only control input that is not rank-uniform, so the verdicts
+ * are summed over the ranks (anybody's time-out ends it for all).  Called at the same control points on every rank. */
+static int time_is_up(lrd_solver *s, double t_start, double limit) {
+    double v = (lrd_time() - t_start >= limit) ? 1.0 : 0.0;
+    if (s->allreduce) BE(s->allreduce(s->allreduce_user, &v, 1, 0));
+    return v > 0.0;
+}
+
 static double inf_from_l1(const lrd_solver *s, double l1) {
     return l1 * (1 + s->prob->bNrm1) / (1 + s->prob->bNrmInf);
 }
@@ -138,14 +151,15 @@ static double l2_from_l1(const lrd_solver *s, double l1) { return l1 * (1 + s->p
 
 static void refresh_obj(lrd_solver *s, int pair) {
     double v = 0.0;
-    s->be->cal_obj(s->be->ctx, pair, &v);
+    BE(s->be->cal_obj(s->be->ctx, pair, &v));
     s->pObjVal = v / s->scaleObjHis;
-    s->be->cal_dual_obj(s->be->ctx, &v);
+    v = 0.0;
+    BE(s->be->cal_dual_obj(s->be->ctx, &v));
     s->dObjVal = v / s->scaleObjHis;
 }
 
 static void refresh_dimacs(lrd_solver *s, int pair) {
-    s->be->update_dimacs(s->be->ctx, pair, &s->err_constr_l1);
+    BE(s->be->update_dimacs(s->be->ctx, pair, &s->err_constr_l1));
     double gap = s->pObjVal - s->dObjVal;
     s->err_pdgap = fabs(gap) / (1 + fabs(s->pObjVal) + fabs(s->dObjVal));
 }
@@ -184,7 +198,7 @@ static int ema_check(double *cur, double *old, double val, double alpha, double 
 }
 
 /* CheckAllRankMax, data/lorads_solver.c:758-774 */
-static int all_rank_max(const lrd_solver *s, double factor) {
+static int all_rank_max(lrd_solver *s, double factor) {
     int cnt = 0;
     for (int k = 0; k < s->prob->nblk; ++k) {
         int nr = (int)LMIN(ceil(s->rank[k] * factor), (double)s->prob->blk[k].rank_max);
@@ -192,7 +206,7 @@ static int all_rank_max(const lrd_solver *s, double factor) {
     }
     if (s->allreduce) { /* blocks are sharded: every rank must take the same decision */
         double v[2] = {(double)cnt, (double)s->prob->nblk};
-        s->allreduce(s->allreduce_user, v, 2, 0);
+        BE(s->allreduce(s->allreduce_user, v, 2, 0));
         return v[0] == v[1];
     }
     return cnt == s->prob->nblk;
@@ -205,7 +219,13 @@ static int augment_rank(lrd_solver *s, double factor) {
     int nb = s->prob->nblk;
     int *nr = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
     for (int k = 0; k < nb; ++k) nr[k] = (int)LMIN(ceil(s->rank[k] * factor), (double)s->prob->blk[k].rank_max);
-    s->be->resize_rank(s->be->ctx, nr);
+    if (s->be->resize_rank(s->be->ctx, nr) != 0) {
+        /* refused (e.g. a rank the device kernels do not cover): host and device keep the OLD ranks -- treated as
+         * "rank cannot grow any further", and flagged so that the caller stops */
+        s->be_fail = 1;
+        free(nr);
+        return 1;
+    }
     for (int k = 0; k < nb; ++k) s->rank[k] = nr[k];
     free(nr);
     return all_rank_max(s, factor);
@@ -236,8 +256,8 @@ int lrd_alm_optimize(lrd_params *par, lrd_solver *s, int reopt, int early_stop, 
 
 restart:
     cert_tol = cert0 / st->rho;
-    be->init_constr(cx, LRD_PAIR_RR);
-    be->alm_cal_grad(cx, st->rho, &lag);
+    BE(be->init_constr(cx, LRD_PAIR_RR));
+    BE(be->alm_cal_grad(cx, st->rho, &lag));
     cert_val = cert(s, lag);
     difficulty = 'h';
     local_iter = 0; clear_lbfgs = 0; rank_flag = 0; rho_factor_flag = 0; sub_counter = 0;
@@ -277,9 +297,9 @@ restart:
                 if ((!reopt && local_iter % 300 == 0) || (reopt && (local_iter - 1) % 300 == 0)) clear_lbfgs = 0;
                 double p12[2], coef[4];
                 if (!fused) {
-                    be->lbfgs_direction(cx, clear_lbfgs);
-                    be->alm_q12p12(cx, p12);
-                    be->alm_linesearch_coeffs(cx, st->rho, p12[0], p12[1], coef);
+                    BE(be->lbfgs_direction(cx, clear_lbfgs));
+                    BE(be->alm_q12p12(cx, p12));
+                    BE(be->alm_linesearch_coeffs(cx, st->rho, p12[0], p12[1], coef));
                 } else {
                     if (!have_front && be->alm_front(cx, st->rho, clear_lbfgs, front)) { ret = LRD_RET_NUM_ERR; goto end_alm; }
                     memcpy(coef, front + 2, sizeof coef);
@@ -294,11 +314,11 @@ restart:
                     break;
                 }
                 if (!fused) {
-                    be->set_y_as_neg_grad(cx);
-                    be->alm_update_var(cx, tau);
-                    be->alm_cal_grad(cx, st->rho, &lag);
-                    be->set_lbfgs_his_two(cx, tau);
-                    be->update_dimacs(cx, LRD_PAIR_RR, &s->err_constr_l1);
+                    BE(be->set_y_as_neg_grad(cx));
+                    BE(be->alm_update_var(cx, tau));
+                    BE(be->alm_cal_grad(cx, st->rho, &lag));
+                    BE(be->set_lbfgs_his_two(cx, tau));
+                    BE(be->update_dimacs(cx, LRD_PAIR_RR, &s->err_constr_l1));
                 } else {
                     /* the counter the next pass of this loop would hand to lbfgs_direction */
                     int next_clear = clear_lbfgs + 1;
@@ -310,6 +330,7 @@ restart:
                     memcpy(front, o + 2, sizeof front);
                     have_front = 1;
                 }
+                if (s->be_fail) { ret = LRD_RET_NUM_ERR; goto end_alm; }
                 { double gap = s->pObjVal - s->dObjVal;
                   s->err_pdgap = fabs(gap) / (1 + fabs(s->pObjVal) + fabs(s->dObjVal)); }
                 st->l_1_primal_infeasibility = s->err_constr_l1;
@@ -325,8 +346,8 @@ restart:
                 if (local_iter > 800) break;
             }
             if (jump_update_rho) break;
-            be->update_dual_var(cx, st->rho);
-            be->alm_cal_grad(cx, st->rho, &lag);
+            BE(be->update_dual_var(cx, st->rho));
+            BE(be->alm_cal_grad(cx, st->rho, &lag));
             cert_val = cert(s, lag);
             if (local_iter <= 20) difficulty = 'e';
             else if (local_iter <= 100) { difficulty = 'm'; rank_flag += 2; }
@@ -337,10 +358,11 @@ restart:
         /* UpdateRho */
         do {
             st->rho *= rho_update_factor;
-            be->alm_cal_grad(cx, st->rho, &lag);
+            BE(be->alm_cal_grad(cx, st->rho, &lag));
             cert_val = cert(s, lag);
             cert_tol = cert0 / st->rho;
-        } while (cert_tol >= cert_val);
+        } while (cert_tol >= cert_val && !s->be_fail);
+        if (s->be_fail) { ret = LRD_RET_NUM_ERR; goto end_alm; }
         if (st->rho >= 5e4 && rho_factor_flag < 4) { rho_update_factor = sqrt(sqrt(rho_update_factor)); rho_factor_flag = 4; }
         else if (st->rho >= 5e6 && rho_factor_flag < 6) { rho_update_factor = sqrt(sqrt(rho_update_factor)); rho_factor_flag = 6; }
         else if (st->rho >= 5e8 && rho_factor_flag < 8) { rho_update_factor = sqrt(sqrt(rho_update_factor)); rho_factor_flag = 8; }
@@ -370,12 +392,13 @@ restart:
             goto print_and_exit;
         }
         alm_log(par, st, lrd_time() - t_ori);
-        if (lrd_time() - t_start >= par->timeSecLimit) goto print_and_exit;
+        if (time_is_up(s, t_start, par->timeSecLimit)) goto print_and_exit;
         if (rank_flag >= rank_thres && !is_rank_max && (!reopt || s->prob->nsdp_global <= 10)) {
             rank_flag = 0;
             if (k - last_outer_start >= 2) {
                 if (par->verbose) printf("increase the rank, factor:%f.\n", rank_factor);
                 is_rank_max = augment_rank(s, rank_factor);
+                if (s->be_fail) { ret = LRD_RET_NUM_ERR; goto end_alm; }
                 st->outerIter = k;
                 last_outer_start = st->outerIter;
                 goto restart;
@@ -397,6 +420,7 @@ end_alm:
     }
     st->l_1_dual_infeasibility = st->l_inf_dual_infeasibility = 99;
 print_and_exit:
+    if (s->be_fail) ret = LRD_RET_NUM_ERR;
     if (par->verbose) {
         printf("-----------------------------------------------------------------------\nExit ALM:\n");
         alm_log(par, st, lrd_time() - t_ori);
@@ -423,7 +447,7 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
     d->rho = LMIN(d->rho, par->rhoMax);
     s->cgIter = 0;
     /* prologue, lorads_admm.c:47-58 */
-    be->init_constr(cx, LRD_PAIR_UV);
+    BE(be->init_constr(cx, LRD_PAIR_UV));
     refresh_obj(s, LRD_PAIR_UV);
     refresh_dimacs(s, LRD_PAIR_UV);
     admm_pull_state(s, 1);
@@ -445,8 +469,8 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
         double cg_tol = LMIN(d->l_1_primal_infeasibility * (reopt ? 1e-4 : 1e-2), 1e-8);
         int cg_its = 0;
         if (be->admm_step && s->use_fused_step) {
-            double o[4];
-            be->admm_step(cx, d->rho, cg_tol, cg_max, o);
+            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            if (be->admm_step(cx, d->rho, cg_tol, cg_max, o) != 0) { s->be_fail = 1; return LRD_RET_NUM_ERR; }
             cg_its = (int)o[0];
             s->pObjVal = o[1] / s->scaleObjHis;
             s->dObjVal = o[2] / s->scaleObjHis;
@@ -455,12 +479,13 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
             s->cgIter += cg_its;
             d->cg_iter = s->cgIter;
         } else {
-            be->admm_update_var(cx, d->rho, cg_tol, cg_max, &cg_its);
+            if (be->admm_update_var(cx, d->rho, cg_tol, cg_max, &cg_its) != 0) { s->be_fail = 1; return LRD_RET_NUM_ERR; }
             s->cgIter += cg_its;
             d->cg_iter = s->cgIter;
             refresh_obj(s, LRD_PAIR_UV);
             refresh_dimacs(s, LRD_PAIR_UV);
         }
+        if (s->be_fail) return LRD_RET_NUM_ERR;
         admm_pull_state(s, reopt); /* the first-pass loop does not refresh l1 here (lorads_admm.c:82-85) */
         d->l_inf_primal_infeasibility = inf_from_l1(s, s->err_constr_l1);
         if (reopt) d->l_2_primal_infeasibility = l2_from_l1(s, s->err_constr_l1);
@@ -483,7 +508,7 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
                 return LRD_RET_OK;
             }
         }
-        be->update_dual_var(cx, d->rho);
+        BE(be->update_dual_var(cx, d->rho));
         /* rho schedule: tested on iter+1 in the first pass, on iter in the reopt pass */
         int it_sched = reopt ? d->iter : d->iter + 1;
         if (it_sched % par->rhoFreq == 0) {
@@ -507,7 +532,7 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
             refresh_dimacs(s, LRD_PAIR_UV);
             admm_pull_state(s, 1);
             admm_log(par, d, lrd_time() - t_ori);
-            if (lrd_time() - t_start >= par->timeSecLimit) return LRD_RET_TIME_OUT;
+            if (time_is_up(s, t_start, par->timeSecLimit)) return LRD_RET_TIME_OUT;
         }
         if (d->primal_dual_gap <= par->phase2Tol * 1e-3 && d->l_1_primal_infeasibility <= par->phase2Tol * 1e-3) {
             if (par->verbose) printf("Early Stop When DIMACS Errors Are Well-Satisfied");
@@ -516,12 +541,12 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
         d->iter++;
     }
     if (reopt) admm_log(par, d, lrd_time() - t_ori);
-    return LRD_RET_OK;
+    return s->be_fail ? LRD_RET_NUM_ERR : LRD_RET_OK;
 }
 
 /* LORADS_ALMtoADMM, data/lorads_solver.c:968-1004 */
 void lrd_alm_to_admm(lrd_params *par, lrd_solver *s) {
-    s->be->alm_to_admm(s->be->ctx);
+    BE(s->be->alm_to_admm(s->be->ctx));
     lrd_alm_state *a = &s->alm;
     lrd_admm_state *d = &s->admm;
     d->l_1_dual_infeasibility = a->l_1_dual_infeasibility;
@@ -546,7 +571,7 @@ double lrd_reopt(lrd_params *par, lrd_solver *s, double reopt_param, int reopt_a
     par->maxALMIter = reopt_alm_iter - 1 + s->alm.outerIter;
     par->maxADMMIter = reopt_admm_iter;
     s->scaleObjHis *= reopt_param; /* objScale_dualvar */
-    s->be->scale_obj(s->be->ctx, reopt_param);
+    BE(s->be->scale_obj(s->be->ctx, reopt_param));
     if (s->admm.rho <= par->rhoMax) s->alm.rho = LMAX(s->admm.rho, s->alm.rho);
     double t0 = lrd_time();
     lrd_alm_optimize(par, s, 1, 1, sqrt(par->ALMRhoFactor), t_start);
@@ -570,7 +595,7 @@ int lrd_dual_infeasibility(lrd_solver *s) {
     if (!s->be->dual_infeasibility) { s->err_dual_l1 = -1.0; return 1; }
     double t = lrd_time(), v = 0.0;
     if (s->be->dual_infeasibility(s->be->ctx, &v)) { s->err_dual_l1 = -1.0; return 1; }
-    if (s->allreduce) s->allreduce(s->allreduce_user, &v, 1, 0);
+    if (s->allreduce) BE(s->allreduce(s->allreduce_user, &v, 1, 0));
     s->err_dual_l1 = v / s->scaleObjHis / (s->prob->cObjNrm1 + 1);
     lrd_admm_state *d = &s->admm;
     d->l_1_dual_infeasibility = s->err_dual_l1;
@@ -594,13 +619,16 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
     s->err_dual_l1 = -1.0;
     s->t_dual_infeas = 0.0;
     double ta = lrd_time();
+    s->be_fail = 0;
     lrd_alm_optimize(par, s, 0, 0, par->ALMRhoFactor, t0);
     s->t_alm = lrd_time() - ta;
-    if (lrd_time() - t0 > par->timeSecLimit) { s->status = LRD_TIME_LIMIT; return 0; }
+    if (s->be_fail) return LRD_RET_NUM_ERR; /* a table slot failed: nothing below would be computed from real numbers */
+    if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
     lrd_alm_to_admm(par, s);
     ta = lrd_time();
     if (lrd_admm_optimize(par, s, 0, par->maxADMMIter, t0) == LRD_RET_BAD_ITER) bad = 1;
     s->t_admm = lrd_time() - ta;
+    if (s->be_fail) return LRD_RET_NUM_ERR;
     s->admm_iters_first = s->admm.iter;
     s->cg_iters_first = s->cgIter;
     const int admm_reopt_min_iter = par->highAccMode ? 1000 : 50;
@@ -612,7 +640,8 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
             if (par->verbose) printf("******  reopt parameter:%.3f\n", 5.0);
             lrd_reopt(par, s, 5.0, 3, admm_reopt_min_iter, t0, &bad, 1);
             cnt += 1;
-            if (lrd_time() - t0 > par->timeSecLimit) { s->status = LRD_TIME_LIMIT; return 0; }
+            if (s->be_fail) return LRD_RET_NUM_ERR;
+            if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
         }
     }
     const int have_dual = lrd_dual_infeasibility(s) == 0; /* main.c:400-413, evaluated at every reoptLevel */
@@ -630,13 +659,14 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
                 break;
             if (par->verbose) printf("******  reopt parameter:%.3f\n", 5.0);
             lrd_reopt(par, s, 5.0, 3, 50, t0, &bad, 2);
-            s->be->average_uv_to_v(s->be->ctx); /* averageUV + copyRtoV, main.c:438-448 */
+            BE(s->be->average_uv_to_v(s->be->ctx)); /* averageUV + copyRtoV, main.c:438-448 */
+            if (s->be_fail) return LRD_RET_NUM_ERR;
             if (lrd_dual_infeasibility(s)) break;
             if (par->verbose)
                 printf("reopt %d:Dual infeasibility: l_1 = %f, l_inf = %f, l_2 = %f\n", dual_cnt, d->l_1_dual_infeasibility,
                        d->l_inf_dual_infeasibility, d->l_2_dual_infeasibility);
             dual_cnt += 1;
-            if (lrd_time() - t0 > par->timeSecLimit) { s->status = LRD_TIME_LIMIT; return 0; }
+            if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
         }
         if (d->l_1_dual_infeasibility <= 5 * par->phase2Tol && d->primal_dual_gap <= 5 * par->phase2Tol &&
             d->l_1_primal_infeasibility <= par->phase2Tol)

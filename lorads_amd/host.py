@@ -366,6 +366,14 @@ class Session:
                 "spmm_sampled_ms"]
         return dict(zip(keys, [out[i] for i in range(8)]))
 
+    def hip_profile_samples(self, cap=4096):
+        """milliseconds of every operator application timed since hip_profile(1, ...) (drains the event pool)"""
+        lib, ctx = self._hip()
+        lib.lorads_hip_profile_samples.argtypes = [C.c_void_p, _dp, C.c_int, _ip]
+        buf, n = (C.c_double * cap)(), C.c_int()
+        _check(lib.lorads_hip_profile_samples(ctx, buf, cap, C.byref(n)), "profile_samples")
+        return [buf[i] for i in range(min(cap, n.value))]
+
     def hip_ubench(self, which, reps):
         """milliseconds of `reps` back-to-back launches of kernel variant `which` (diagnostic, see lorads_hip.h)"""
         lib, ctx = self._hip()
