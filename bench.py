@@ -299,7 +299,7 @@ def install_allreduce(s, dist, torch, device, world, rank, backend):
     return mode, seen[0]
 
 
-def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0):
+def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0, ranks=None):
     """Times the CPU path on the host cores, rank 0 / N = 1 only: the compiled reference
     (oracle/_ref, kind "reference") when it is present, else the plain-C restatement (kind "port").
     A cone with n^2 > 2^31 (cfg5) overflows the packed index of the reference's default 32-bit build
@@ -310,6 +310,8 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0):
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
     if wide:
         env["MKL_INTERFACE_LAYER"] = "ILP64"
+    if ranks:   # the device's phase 1 may have grown the ranks (AUG_RANK): the reference must load factors of that shape
+        env["LORADS_REF_UV_RANKS"] = ",".join(str(int(r)) for r in ranks)
     if os.path.exists(drv):
         try:
             its = 2
@@ -344,6 +346,8 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0):
     try:
         raw = np.fromfile(state_file, dtype=np.float64)
         o = 0
+        if ranks and [s.block_shape(k)[1] for k in range(s.nblk)] != list(ranks):
+            s.be.resize_rank(list(ranks))
         for k in range(s.nblk):
             n, r = s.block_shape(k)
             s.be.set_mat(host.MAT_U, k, raw[o:o + n * r].reshape(r, n).T)
@@ -425,6 +429,8 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     be.init_constr(host.PAIR_UV)
     be.cal_obj(host.PAIR_UV)
     err1 = be.update_dimacs(host.PAIR_UV)
+    r_start = info["rank"]
+    info = s.block_info(0)   # (phase 1 may have grown the rank)
     log("rank %d: phase 1 took %.2fs (%d inner its), rho=%.4g err1=%.3e, %d local cone(s), n=%d r=%d" %
         (rank, time.time() - t0, int(res["alm_inner"]), rho, err1, nloc, info["n"], info["rank"]))
     state_file = "/tmp/lorads_bench_state_%d.bin" % os.getpid()
@@ -534,7 +540,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             "cg_iters_per_s": cg_iters / elapsed,
             "cg_iters_per_admm_iter": cg_iters / units,
             "config": {"workload": cfg_txt,
-                       "n": info["n"], "r": info["rank"], "m_per_block": info["nrow"], "blocks": s.nblk_global,
+                       "n": info["n"], "r": info["rank"], "r_at_start": r_start, "m_per_block": info["nrow"], "blocks": s.nblk_global,
                        "parallelism": ("%s, 1 all-reduce of the shared m-vector per ADMM iteration (%s)"
                                        % ("cones dealt over the ranks" if strong else "block-per-GPU", ar_mode)) if world > 1 else "single GPU",
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (tlr, rho)},
@@ -588,7 +594,8 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
                 "frac_events": fused / (mv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if achieved else None}
         if world == 1 and with_cpu:
             try:
-                cb = cpu_baseline(path, tlr, rho, state_file, a.cpu_budget, log, n_max=info["n"])
+                cb = cpu_baseline(path, tlr, rho, state_file, a.cpu_budget, log, n_max=info["n"],
+                                  ranks=[s.block_info(k)["rank"] for k in range(nloc)])
                 cb["host_cores_total"] = os.cpu_count()
                 try:
                     with open("/proc/cpuinfo") as fh:

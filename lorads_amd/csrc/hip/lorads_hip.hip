@@ -1242,8 +1242,10 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
 
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *c, int32_t k, double *mv, double *cg) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
-    *mv = c->blk[k].bytes_mv;
-    *cg = c->blk[k].bytes_cg;
+    const Block &B = c->blk[k]; // (from the CURRENT rank: phase 1 may have grown it since the cone was built)
+    const double F = 8.0 * (double)B.n * (double)B.r;
+    *mv = 4 * F + 32.0 * B.na + 16.0 * B.nrow;
+    *cg = *mv + 9 * F;
     return 0;
 }
 

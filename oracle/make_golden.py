@@ -59,6 +59,12 @@ SOLVE = [
     ("coupledlp", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("maxcut800", ["--reoptLevel", "0"]),
     ("maxcut800", ["--reoptLevel", "0", "--phase1Tol", "1e-2"]),
+    # north-star wording: converged objectives to 1e-6 relative -- runs that converge well below that
+    ("maxcut800", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),                       # cfg2 look-alike
+    ("theta50", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),                         # cfg1 look-alike
+    ("maxcut800", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-8"]),
+    ("rand120", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),
+    ("blk4x60", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),
 ]
 
 

@@ -372,6 +372,25 @@ static int mode_admm_bench(ctx_t *c, lorads_params *p, int n_admm, const char *u
     lorads_func *f;
     LORADSInitFuncSet(&f, S->nLpCols);
     int nb = (int)c->nBlks;
+    /* LORADS_REF_UV_RANKS="r0,r1,...": the factors in the file have these ranks (the run that wrote them grew its ranks in
+     * phase 1).  The reference grows ranks by AUG_RANK steps of factor 1.5 (lorads_alm.c:1007,1232): apply that step until the
+     * solver's buffers have the file's shape (refused if the file's ranks are not reachable that way). */
+    const char *want = getenv("LORADS_REF_UV_RANKS");
+    if (uvfile && want && *want) {
+        for (int guard = 0; guard < 16; ++guard) {
+            int ok = 1, over = 0;
+            const char *q = want;
+            for (int k = 0; k < nb; ++k) {
+                long t = strtol(q, (char **)&q, 10);
+                if (*q == ',') ++q;
+                if (S->var->U[k]->rank < t) ok = 0;
+                if (S->var->U[k]->rank > t) over = 1;
+            }
+            if (over) { fprintf(stderr, "LORADS_REF_UV_RANKS: not reachable by AUG_RANK steps\n"); return 1; }
+            if (ok) break;
+            AUG_RANK(S, S->var->rankElem, c->nBlks, 1.5);
+        }
+    }
     if (uvfile) {
         FILE *fp = fopen(uvfile, "rb");
         if (!fp) { fprintf(stderr, "cannot open %s\n", uvfile); return 1; }

@@ -917,24 +917,34 @@ def test_fullsize_admm_vs_compiled_reference(built):
 @pytest.mark.skipif(os.environ.get("LORADS_SKIP_LONG_TESTS") == "1", reason="~20 s of reference CPU time per instance on the GPU box's host")
 @pytest.mark.parametrize("name,tlr,shape", [("maxcut20000", 4.0, (20000, 40)), ("rand20000", 4.0, (20000, 40)),
                                             ("blk16x4000", 2.0, (4000, 17)), ("matcomp4000", 2.0, (4000, 17)),
-                                            ("sdplp2000", 2.0, (2000, 16))])
+                                            ("sdplp2000", 2.0, (2000, 16)), ("matcomp50000", 5.5, (50000, 60))])
 def test_fullsize_trace_vs_compiled_reference(built, name, tlr, shape):
     """Every lorads_func slot at BASELINE size (cfg3a, cfg3b: n = 20000, r = 40; cfg4: 16 cones n = 4000, the merged-cone /
-    lockstep path) against vectors the compiled reference produces on the spot: oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
-    2 ADMM iterations), replayed through the C ABI exactly like the small golden traces."""
-    drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver")
+    lockstep path; cfg5: n = 50000, r = 60, m = 2e5) against vectors the compiled reference produces on the spot:
+    oracle/_ref/ref_driver in `trace` mode (3 ALM inner iterations, the reference's own phase 1 as warm start,
+    2 ADMM iterations), replayed through the C ABI exactly like the small golden traces.
+    cfg5 needs the reference's 64-bit index build (oracle/Makefile ref64: the 32-bit default cannot read n = 50000) and
+    skips the reference's own phase 1 between the two parts (hours on one core): its ADMM part starts from the state
+    the three traced ALM iterations left -- the same functions on the same inputs."""
+    wide = shape[0] * shape[0] > 2**31 - 1
+    drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver64" if wide else "ref_driver")
     if not os.path.exists(drv):
         pytest.skip("oracle/_ref not built")
     path = _gen(name)
     dump = "/tmp/lorads_test_trace_%d.bin" % os.getpid()
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", LORADS_REF_ALLOW_LP="1")
-    r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", "2", "--timesLogRank", repr(tlr), "--phase1Tol", "1e-2"],
+    if wide:
+        env.update(MKL_INTERFACE_LAYER="ILP64", LORADS_REF_NO_WARM="1")
+    # (cfg5 without the reference's phase 1: ONE ADMM iteration -- from that cold state the second one runs into the CG
+    # iteration limit on both sides and pins nothing; iteration 0 exercises both solves, refreshes, objective, dual update)
+    n_admm = 1 if wide else 2
+    r = subprocess.run([drv, path, "trace", dump, "--nALM", "3", "--nADMM", str(n_admm), "--timesLogRank", repr(tlr), "--phase1Tol", "1e-2"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-400:]
     g = common.read_dump(dump)
     os.remove(dump)
     g["_nALM"] = np.array([3.0])
-    g["_nADMM"] = np.array([2.0])
+    g["_nADMM"] = np.array([float(n_admm)])
     s = common.hip_session(path, timesLogRank=tlr, phase1Tol=1e-2)
     try:
         assert s.block_shape(0) == shape
@@ -943,3 +953,83 @@ def test_fullsize_trace_vs_compiled_reference(built, name, tlr, shape):
         print(name, "records", len(log), "worst rel-to-scale error", worst)
     finally:
         s.close()
+
+
+def test_cfg5_slots_vs_oracle_fullsize(built):
+    """BASELINE cfg5 (matrix completion n = 50000, m = 2e5 single-entry constraints, r = 60: k_op_entry and the phase-1
+    kernels at the size the config names) slot by slot against the CPU oracle from the same state: 3 ALM inner
+    iterations, then 2 ADMM iterations with their CG solves.  Independent of the reference build (the oracle needs none);
+    the oracle's cost here is O(P r) per slot: about a minute in all."""
+    path = _gen("matcomp50000")
+    hs, os_ = _pair(path, timesLogRank=5.5)
+    try:
+        assert hs.block_shape(0) == (50000, 60) and hs.m == 200000
+        assert hs.hip_operator_kind(0) == "k_op_entry"
+        rho = 0.5
+        for it in range(3):
+            vals = []
+            for s in (hs, os_):
+                be = s.be
+                if it == 0:
+                    be.init_constr(host.PAIR_RR)
+                lag = be.alm_cal_grad(rho)
+                be.lbfgs_direction(it)
+                p1, p2 = be.alm_q12p12()
+                k = be.alm_linesearch_coeffs(rho, p1, p2)
+                vals.append((lag, p1, p2, k, be.get_mat(host.MAT_U, 0), be.get_vec(host.VEC_Q1), be.get_vec(host.VEC_Q2),
+                             be.get_mat(host.MAT_GRAD, 0)))
+            (la, p1a, p2a, ka, Da, q1a, q2a, Ga), (lb, p1b, p2b, kb, Db, q1b, q2b, Gb) = vals
+            assert np.isclose(la, lb, rtol=1e-10)
+            assert np.isclose(p1a, p1b, rtol=1e-9, atol=1e-9 * abs(p2b))
+            assert np.isclose(p2a, p2b, rtol=1e-9)
+            assert np.allclose(ka, kb, rtol=1e-8, atol=1e-9 * max(abs(x) for x in kb))
+            assert np.allclose(Ga, Gb, rtol=0, atol=1e-10 * np.abs(Gb).max())
+            assert np.allclose(Da, Db, rtol=0, atol=1e-9 * np.abs(Db).max())
+            assert np.allclose(q1a, q1b, rtol=0, atol=1e-10 * np.abs(q1b).max())
+            assert np.allclose(q2a, q2b, rtol=0, atol=1e-10 * np.abs(q2b).max())
+            tau, _ = common.linesearch_tau(kb)
+            for s in (hs, os_):
+                be = s.be
+                be.set_y_as_neg_grad()
+                be.alm_update_var(tau)
+                be.alm_cal_grad(rho)
+                be.set_lbfgs_his_two(tau)
+            ea, eb = hs.be.update_dimacs(host.PAIR_RR), os_.be.update_dimacs(host.PAIR_RR)
+            assert np.isclose(ea, eb, rtol=1e-9)
+            Ra, Rb = hs.be.get_mat(host.MAT_R, 0), os_.be.get_mat(host.MAT_R, 0)
+            assert np.allclose(Ra, Rb, rtol=0, atol=1e-11 * np.abs(Rb).max())
+            hs.be.set_mat(host.MAT_R, 0, Rb)  # identical states: errors do not compound
+        for s in (hs, os_):
+            s.be.update_dual_var(rho)
+            s.be.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+        la, lb = hs.be.get_vec(host.VEC_LAMBDA), os_.be.get_vec(host.VEC_LAMBDA)
+        assert np.allclose(la, lb, rtol=0, atol=1e-11 * np.abs(lb).max())
+        rho2 = 2.0
+        for it in range(2):
+            ia = hs.be.admm_update_var(rho2, 1e-7, 800)
+            ib = os_.be.admm_update_var(rho2, 1e-7, 800)
+            assert abs(ia - ib) <= max(2, 0.03 * ib), (ia, ib)
+            Ua, Ub = hs.be.get_mat(host.MAT_U, 0), os_.be.get_mat(host.MAT_U, 0)
+            Va, Vb = hs.be.get_mat(host.MAT_V, 0), os_.be.get_mat(host.MAT_V, 0)
+            assert np.allclose(Ua, Ub, rtol=0, atol=2e-6 * np.abs(Ub).max())
+            assert np.allclose(Va, Vb, rtol=0, atol=2e-6 * np.abs(Vb).max())
+            ca, cb = hs.be.get_vec(host.VEC_CONSTR_SUM), os_.be.get_vec(host.VEC_CONSTR_SUM)
+            assert np.allclose(ca, cb, rtol=0, atol=2e-6 * np.abs(cb).max())
+            pa, pb = hs.be.cal_obj(host.PAIR_UV), os_.be.cal_obj(host.PAIR_UV)
+            assert np.isclose(pa, pb, rtol=1e-6)
+            da, db = hs.be.cal_dual_obj(), os_.be.cal_dual_obj()
+            assert np.isclose(da, db, rtol=1e-9)
+            ea, eb = hs.be.update_dimacs(host.PAIR_UV), os_.be.update_dimacs(host.PAIR_UV)
+            assert np.isclose(ea, eb, rtol=1e-4, atol=1e-9)
+            hs.be.set_mat(host.MAT_U, 0, Ub)
+            hs.be.set_mat(host.MAT_V, 0, Vb)
+            hs.be.update_dimacs(host.PAIR_UV)  # constrVal / constrValSum of the synchronised pair (quirk Q1: A(R R^T))
+            for s in (hs, os_):
+                s.be.update_dual_var(rho2)
+            la, lb = hs.be.get_vec(host.VEC_LAMBDA), os_.be.get_vec(host.VEC_LAMBDA)
+            assert np.allclose(la, lb, rtol=0, atol=1e-9 * np.abs(lb).max())
+            print("cfg5 ADMM iteration", it, "cg", ia, ib, "pObj", pa, pb, "err1", ea, eb)
+    finally:
+        hs.close()
+        os_.close()
