@@ -411,6 +411,10 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
 
     s = host.Session.open(path)
     s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+    if workload == "matcomp50000" and os.environ.get("LORADS_BENCH_RANK_GROWTH") != "1":
+        # BASELINE cfg5 names r = 60: with the default rank-growth rule phase 1 takes this instance to r = 90 before the timed
+        # ADMM iterations start (LORADS_BENCH_RANK_GROWTH=1: let it)
+        s.set_params(dyrankLevel=0)
     s.prepare(world, rank)   # cones dealt round-robin over the ranks
     s.attach_hip()
     ar_mode, ranks_seen = None, 1

@@ -61,7 +61,8 @@ SOLVE = [
     ("maxcut800", ["--reoptLevel", "0", "--phase1Tol", "1e-2"]),
     # north-star wording: converged objectives to 1e-6 relative -- runs that converge well below that
     ("maxcut800", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),                       # cfg2 look-alike
-    ("theta50", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),                         # cfg1 look-alike
+    # (theta50, the cfg1 look-alike, does not get that far in the reference: 20000 ADMM iterations and a gap of 5e-5 at
+    #  --phase2Tol 1e-8 -- its golden stays the 1e-7 run above, compared at the level the reference reached)
     ("maxcut800", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-8"]),
     ("rand120", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),
     ("blk4x60", ["--reoptLevel", "1", "--phase2Tol", "1e-8"]),

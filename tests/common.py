@@ -177,7 +177,12 @@ def replay_trace(sess, g, rtol=1e-9, atol=1e-13, resync=True):
         _cmp("admm_pobj_%d" % it, pobj, sc[0], cg_rtol, atol, log)
         _cmp("admm_dobj_%d" % it, dobj, sc[1], cg_rtol, atol, log)
         _cmp("admm_err1_%d" % it, l1, sc[2], cg_rtol * 10, 1e-12, log)
-        if abs(cg_total - sc[4]) > max(3, 0.02 * sc[4]):
+        # sparse-mode runs (no dense scratch matrix anywhere: the reference sums in the same sparse order): the CG must stop at
+        # the same iteration as the reference's; the reference's dense branch rounds differently, so a test that sits on the
+        # threshold may fall the other way there
+        dense_mode = bool(np.any(np.asarray(g.get("wsum_is_dense", [0.0])) > 0))
+        slack = max(3, 0.02 * sc[4]) if dense_mode else 0
+        if abs(cg_total - sc[4]) > slack:
             raise Mismatch("cg iterations %d vs reference %d at ADMM it %d" % (cg_total, sc[4], it))
         log.append(("cg_iters_%d" % it, abs(cg_total - sc[4])))
         _cmp("csum_rr_%d" % it, be.get_vec(host.VEC_CONSTR_SUM), g["csum_rr_%d_0" % it], cg_rtol, atol, log)

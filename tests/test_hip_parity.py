@@ -109,20 +109,36 @@ def _flags_to_params(flags):
 
 @pytest.mark.parametrize("idx", range(len(common.golden_solves())))
 def test_whole_solve_vs_reference(built, idx):
-    """converged objectives / DIMACS errors against the reference's own runs (north_star: 1e-6 relative
-    where the reference itself is converged that far; tolerance written below)"""
+    """Whole solves against the reference's own runs of the same command (tests/golden/solve.json), in the north-star's
+    wording: converged objectives to 1e-6 relative, DIMACS errors no worse than the reference's, and -- where the
+    reference's run is in sparse mode and has no reopt round (a few thousand iterations at most: rounding has not yet
+    separated the two trajectories) -- the SAME phase-1 inner / ADMM / CG iteration counts, i.e. every stopping, rho and
+    restart decision taken alike.  profiles/tools/solve_parity_report.py prints the numbers behind these assertions."""
     e = common.golden_solves()[idx]
-    s = common.hip_session(common.instance_path(e["instance"]), **_flags_to_params(e["flags"]))
+    params = _flags_to_params(e["flags"])
+    s = common.hip_session(common.instance_path(e["instance"]), **params)
     try:
         r = s.solve()
     finally:
         s.close()
     ref_gap = abs(e["pObj"] - e["dObj"]) / (1 + abs(e["pObj"]) + abs(e["dObj"]))
-    loose = e["instance"] in ("matcomp60", "theta50")  # see tests/test_oracle_vs_reference.py
-    tol = max(5e-5 if loose else 2e-6, 5 * ref_gap)
+    # two instances where the reference's dense branch (dsyr2k / dsymm rounding) sends phase 1 down another path and the
+    # rank-constrained problem has more than one point meeting the stopping rule (see tests/test_oracle_vs_reference.py)
+    loose = e["instance"] in ("matcomp60", "theta50")
+    tol = max(5e-4 if loose else 1e-6, 5 * ref_gap)
     assert abs(r["pObj"] - e["pObj"]) <= tol * (1 + abs(e["pObj"])), (r["pObj"], e["pObj"])
     assert abs(r["dObj"] - e["dObj"]) <= tol * (1 + abs(e["dObj"])), (r["dObj"], e["dObj"])
-    assert r["constrVio1"] <= max(10 * e["err_constr_l1"], 1e-5)
+    p2 = params.get("phase2Tol", 1e-5)
+    k = 3.0 if loose else 2.0
+    assert r["constrVio1"] <= max(k * e["err_constr_l1"], p2), (r["constrVio1"], e["err_constr_l1"])
+    assert r["pdGap"] <= max(k * e["err_pdgap"], 5 * p2), (r["pdGap"], e["err_pdgap"])
+    dense = e["wsum_is_dense"] if isinstance(e["wsum_is_dense"], list) else [e["wsum_is_dense"]]
+    if all(x == 0 for x in dense) and e["reopt_rounds"] == 0:
+        assert abs(r["pObj"] - e["pObj"]) <= 1e-9 * (1 + abs(e["pObj"]))
+        assert abs(r["dObj"] - e["dObj"]) <= 1e-9 * (1 + abs(e["dObj"]))
+        assert int(r["alm_inner"]) == int(e["alm_inner"]), (r["alm_inner"], e["alm_inner"])
+        assert int(r["admm_iter"]) == int(e["admm_iter"]), (r["admm_iter"], e["admm_iter"])
+        assert int(r["cg_iter"]) == int(e["admm_cg_iter"]), (r["cg_iter"], e["admm_cg_iter"])
 
 
 def test_linearity_and_symmetry_of_operator_fullsize(built):
