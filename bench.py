@@ -449,7 +449,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
 
     # ---- warm-up, then exactly K timed steps
     err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup, s)
-    s.hip_profile(1, a.sample_every)
+    s.hip_profile(1, a.sample_every if a.sample_every > 0 else 1 << 30)   # (counts applications either way)
     s.hip_sync()
     if dist:
         dist.barrier()
@@ -541,6 +541,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             "dtype": "f64", "data": "synthetic",
             "ranks_seen": ranks_seen,
             "admm_iters_per_s_of_the_sharded_problem": a.steps / elapsed,
+            "speculation_misses_in_timed_region": int(prof["matvec_ms_est"]),   # (solves resumed after a host round trip)
             "cg_iters_per_s": cg_iters / elapsed,
             "cg_iters_per_admm_iter": cg_iters / units,
             "config": {"workload": cfg_txt,
@@ -697,7 +698,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Max-Cut n=20000 companion run")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--sample-every", type=int, default=8, help="time every n-th operator application with HIP events")
+    ap.add_argument("--sample-every", type=int, default=0, help="time every n-th operator application with HIP events INSIDE the "
+                    "timed region (0 = none there: the roofline figures come from the untimed pass after it, and a timed "
+                    "application always takes the operator's general form, which the headline's iteration 0 otherwise shortcuts)")
     ap.add_argument("--windows", type=int, default=5, help="after the timed region: this many further windows of --steps "
                     "steps (reported as ms_per_step_windows / _median; the headline value is the FIRST window)")
     ap.add_argument("--roofline-samples", type=int, default=200, help="untimed pass after the timed region: every operator "

@@ -395,6 +395,16 @@ struct Block {
     int *cell_col = nullptr, *cell_con = nullptr;
     double *cell_a = nullptr;
     double *w_uv = nullptr, *w_op = nullptr; // A(sym(U V^T)) kept for re-use (valid <=> t_uv_valid); operator scratch
+    // k_front_cw (the whole front of a solve without a coefficient pass): the objective's own adjacency row -> (neighbour, c),
+    // constraint -> positions of its slots in the CSR slot list (k_wsum), one contribution per slot
+    bool front_cw = false;
+    int *fc_ptr = nullptr, *fc_col = nullptr;
+    double *fc_val = nullptr;
+    int fc_nslot = 0;
+    int cs_w = 0;             // slots per constraint in the contribution array (fixed width, padding stays 0)
+    int *cell_dst = nullptr, *cadj_dst = nullptr; // slot (fixed-width / CSR numbering) -> its place in the contribution array
+    double *w_contrib = nullptr;
+    bool w0_ready = false;    // w_contrib holds the contributions of A(sym(r0 V^T)) for the residual the front has just left in cr
     bool is_lp = false;       // the LP block: generic diagonal cone everywhere except the ADMM update (k_lp_sweep)
     int lp_nlev = 0;
     int *lp_lvl_ptr = nullptr, *lp_lvl_cols = nullptr, *lp_ptr = nullptr, *lp_grow = nullptr;
@@ -402,7 +412,9 @@ struct Block {
     bool entry_only = false;  // every A_i is a single (off-)diagonal entry (matrix completion): k_op_entry
     double *gentry = nullptr; // sum of a_i^2 per A-pattern entry
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
-    int spec[2] = {1, 1};     // speculated CG iterations of the U- and V-solve
+    int spec[2] = {1, 1};     // speculated CG iterations of the U- and V-solve: the largest count of the last few sweeps
+    int spec_hist[2][8] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
+    int spec_pos = 0;
     double bytes_mv = 0, bytes_cg = 0;
 };
 
@@ -432,6 +444,9 @@ struct lorads_hip_ctx {
     int seg_nvt = 0;
     int *phase_done = nullptr;                // [2]
     int spec_b[2] = {1, 1};                   // speculated lockstep iterations of the U and V phase
+    int spec_b_hist[2][8] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
+    int spec_b_pos = 0;
+    int spec_window = 4;                      // sweeps looked back at (LORADS_SPEC_WINDOW, 1 = the previous sweep's count alone)
     bool merged_ok = false;   // structure allows it (separable constraints, no dense C); ranks decide has_merged
     size_t all_elem = 0;
     double *R = nullptr, *U = nullptr, *V = nullptr, *G = nullptr;   // flat factors
@@ -456,6 +471,10 @@ struct lorads_hip_ctx {
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
+    bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
+    bool avg_folded = false;  // ... and has done so for the evaluation that is enqueued next
+    bool opt_front_cw = true; // k_front_cw + k_wsum instead of k_sval + k_spmm2<FRONT> + iteration 0's k_cw (LORADS_FRONT_CW=0: the latter)
+    bool pend_dual_virtual = false; // the pending dual update has already been USED (formed on the fly by k_front_cw) but not stored
     bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
     bool final_pending = false;              // an evaluation's closing sums wait for the next hand-over (k_publish_final)
     EvalFinalArgs final_args;
@@ -557,6 +576,9 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
+    c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
+    if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
+    c->opt_fold_avg = !(getenv("LORADS_FOLD_AVG") && getenv("LORADS_FOLD_AVG")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
@@ -590,6 +612,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
+        hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
@@ -978,6 +1001,7 @@ int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
         if (B.nc) LAUNCH(k_scale, grid1d((size_t)B.nc), (size_t)B.nc, s, B.c_val);
         if (B.pu.ne) LAUNCH(k_scale, grid1d((size_t)B.pu.ne), (size_t)B.pu.ne, s, B.pu.cbase);
         if (B.pu.nslot) LAUNCH(k_scale, grid1d((size_t)B.pu.nslot), (size_t)B.pu.nslot, s, B.pu.adj_sval); // (the list's own copy of C)
+        if (B.fc_nslot) LAUNCH(k_scale, grid1d((size_t)B.fc_nslot), (size_t)B.fc_nslot, s, B.fc_val); // (k_front_cw's copy)
         if (B.dense_c) LAUNCH(k_scale, grid1d((size_t)B.npad * B.npad), (size_t)B.npad * B.npad, s, B.Cfull);
         if (B.is_lp && B.n) LAUNCH(k_scale, grid1d((size_t)B.n), (size_t)B.n, s, B.lp_cobj);
     }

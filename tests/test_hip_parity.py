@@ -698,6 +698,71 @@ def test_recurrence_and_fused_front_equal_two_pass_form(built, name, steps):
             assert np.allclose(x, y, rtol=0, atol=1e-8 * max(np.abs(y).max(), 1e-300))
 
 
+@pytest.mark.parametrize("name,steps,tlr", [("rand120", 40, None), ("coupled3x70", 12, None), ("sdplp40", 12, None), ("rand4000", 12, 3.0)])
+def test_one_kernel_front_equals_coefficient_pass_plus_fused_front(built, name, steps, tlr):
+    """k_front_cw (right-hand side, initial residual AND the per-slot contributions of iteration 0's constraint weights in
+    one kernel, coefficients formed on the fly from the m-vectors; k_wsum instead of iteration 0's k_cw) against the form
+    it replaces (LORADS_FRONT_CW=0: k_sval, k_spmm2<FRONT>, k_cw): the same sums in another order.  Same CG iteration
+    counts, objectives to 1e-9, factors to 1e-9 of their scale, over sweeps that take 0, a few and > 20 CG iterations,
+    through the fused step and through the slot-by-slot entry points, with the dual update riding on the front."""
+    golden = tlr is None
+    if golden:
+        g = common.golden_trace(name)
+        os.environ["LORADS_OP_CW"] = "1"
+    res = []
+    try:
+        for knob in ("1", "0"):
+            os.environ["LORADS_FRONT_CW"] = knob
+            try:
+                s = common.hip_session(common.instance_path(name)) if golden else common.hip_session(_gen(name), timesLogRank=tlr, phase1Tol=1e-2)
+            finally:
+                os.environ.pop("LORADS_FRONT_CW", None)
+            try:
+                assert "k_cw+k_spmm_ell" in {s.hip_operator_kind(k) for k in range(s.nblk)}
+                if golden:
+                    rank_warm = [int(x) for x in g["rank_warm"]]
+                    if rank_warm != [s.block_shape(k)[1] for k in range(s.nblk)]:
+                        s.be.resize_rank(rank_warm)
+                    for k in range(s.nblk):
+                        n, r = s.block_shape(k)
+                        s.be.set_mat(host.MAT_R, k, g["R_warm_0_%d" % k].reshape(r, n).T)
+                    s.be.set_vec(host.VEC_LAMBDA, g["lambda_warm"])
+                    s.be.alm_to_admm()
+                    rho = float(g["admm_rho"][0])
+                else:
+                    s.alm()
+                    s.alm_to_admm()
+                    rs = s.results()
+                    rho = min(rs["admm_rho"] if rs["admm_rho"] > 0 else rs["alm_rho"], 5000.0)
+                s.be.init_constr(host.PAIR_UV)
+                log = []
+                tols = [1e-8, 1e-3, 1e-13, 1e-6, 1e-1, 1e-10]
+                for it in range(steps):
+                    if it % 3 == 2:
+                        c = s.be.admm_update_var(rho, tols[it % len(tols)], 800)
+                        p, d, e = s.be.cal_obj(host.PAIR_UV), s.be.cal_dual_obj(), s.be.update_dimacs(host.PAIR_UV)
+                    else:
+                        c, p, d, e = s.be.admm_step(rho, tols[it % len(tols)], 800)
+                    s.be.update_dual_var(rho)
+                    log.append((c, p, d, e))
+                res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)], [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)],
+                            s.be.get_vec(host.VEC_LAMBDA)))
+            finally:
+                s.close()
+    finally:
+        os.environ.pop("LORADS_OP_CW", None)
+    (la, Ua, Va, lama), (lb, Ub, Vb, lamb) = res
+    for it, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x[0] - y[0]) <= max(1, 0.02 * y[0]), (it, "cg iterations", x[0], y[0])
+        assert x[1] == pytest.approx(y[1], rel=1e-9, abs=1e-11), (it, "pObj", x[1], y[1])
+        assert x[2] == pytest.approx(y[2], rel=1e-9, abs=1e-11), (it, "dObj", x[2], y[2])
+        assert x[3] == pytest.approx(y[3], rel=1e-6, abs=1e-12), (it, "err1", x[3], y[3])
+    assert np.allclose(lama, lamb, rtol=0, atol=1e-9 * max(np.abs(lamb).max(), 1e-300))
+    for A, B in ((Ua, Ub), (Va, Vb)):
+        for x, y in zip(A, B):
+            assert np.allclose(x, y, rtol=0, atol=1e-9 * max(np.abs(y).max(), 1e-300))
+
+
 @pytest.mark.parametrize("name,cw,nobatch", [("rand120", "1", False), ("maxcut100", None, False), ("coupled3x70", "1", False),
                                              ("mix4", None, False), ("mix4", None, True), ("blk4x60", None, True),
                                              ("sdplp40", "1", False)])
