@@ -490,7 +490,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         win_ms.append(1e3 * w / a.steps)
     # ---- untimed roofline pass: EVERY operator application between two HIP events until enough samples exist, then the
     # live operator back to back with nothing riding along (ubench variant 200: boundaries included, no event latency)
-    roof_samples, alone_ms = [], None
+    roof_samples, alone_ms, kern_ms = [], None, {}
     if a.roofline_samples > 0:
         per_step = prof["matvec_launches"] / max(a.steps, 1)
         if dist:   # every rank must run the same number of (collective-carrying) iterations
@@ -511,6 +511,15 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             alone_ms = s.hip_ubench(200, reps) / reps
         except Exception as e:  # noqa: BLE001
             log("rank %d: back-to-back operator run unavailable: %s" % (rank, e))
+        # cones on the k_cw path at the headline shape: the kernels an ADMM iteration actually launches, back to back
+        # (k_front_cw with and without its second visit of the slots, k_wsum, k_spmm_ell)
+        kern_ms = {}
+        for wv, nm in ((30, "k_front_cw"), (31, "k_front_cw_without_second_visit"), (32, "k_wsum"), (2, "k_spmm_ell"), (1, "k_cw")):
+            try:
+                kern_ms[nm] = s.hip_ubench(wv, 200) / 200
+            except Exception:  # noqa: BLE001  (another cone kind / rank: these variants do not apply)
+                kern_ms = {}
+                break
     b_mv = b_cg = 0.0
     for k in range(nloc):
         x, y = s.hip_algorithmic_bytes(k)
@@ -571,6 +580,24 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
                          "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
                          "traffic": None},
         }
+        if kern_ms:
+            F = 8.0 * info["n"] * info["rank"]
+            na, nc, m_ = info["na"], info["nc"], info["nrow"]
+            b_rhs = 16.0 * (nc + na) + 8.0 * m_ + 3.0 * F          # assemble S, S V, fuse -rho V and 1 / rho
+            b_half = 2.0 * F + 16.0 * na + 8.0 * m_                # the A(sym(x V^T)) half of an operator application
+            k0 = (kern_ms["k_front_cw"] - kern_ms["k_front_cw_without_second_visit"]) + kern_ms["k_wsum"] + kern_ms["k_spmm_ell"]
+            out["roofline"]["iteration0_form"] = {
+                "what": "the operator application of CG iteration 0 as the timed iterations run it (p_0 = r_0): the constraint "
+                        "weights come from the front's second visit of the slots + k_wsum, then k_spmm_ell; kernels back to back",
+                "avg_ms": k0, "frac": b_mv / (k0 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "general_form_ms": kern_ms["k_cw"] + kern_ms["k_spmm_ell"], "kernels_ms": kern_ms}
+            out["roofline_dominant_kernel"] = {
+                "kernel": "k_front_cw (right-hand side + initial residual + slot contributions of a CG solve; the largest share of an "
+                          "ADMM iteration's kernel time)", "bound": "hbm",
+                "algorithmic_bytes_per_launch": b_rhs + b_mv + b_half, "avg_launch_ms": kern_ms["k_front_cw"],
+                "achieved": (b_rhs + b_mv + b_half) / (kern_ms["k_front_cw"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (b_rhs + b_mv + b_half) / (kern_ms["k_front_cw"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "how": "200 launches back to back between one event pair (lorads_hip_ubench 30); B_rhs + B_mv + half of B_mv, SURVEY 8d"}
         # committed rocprofv3 / PMC summaries of this same command: replayed ONLY when their stamp matches the HIP sources
         # of this run (a profile of older kernels is not this run's evidence)
         tr, tsrc = traffic_from_profiles(workload)

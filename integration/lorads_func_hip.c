@@ -9,8 +9,8 @@
  * Built as a shared object that is linked (or LD_PRELOADed) AHEAD of the reference's objects, the dynamic linker binds the
  * reference's calls to these definitions (ordinary ELF symbol interposition: the reference is position-independent code with
  * default visibility), so LORADS_ALMOptimize, LORADSADMMOptimize, their _reopt variants, reopt() and main() run UNCHANGED --
- * not one line of the reference is edited.  integration/reference_call_sites.patch shows the same wiring as source edits for
- * a maintainer who prefers a compile-time switch.
+ * not one line of the reference is edited.  (A maintainer who prefers a compile-time switch adds one branch to
+ * LORADSInitFuncSet and an `if (use_hip)` at the call sites listed below; the functions to call are the ones in this file.)
  *
  * Built only in the build container, against the reference's headers where they lie (oracle/Makefile, target ref_hip ->
  * oracle/_ref_hip/, git-ignored); tests/test_reference_shim.py runs the reference's own loops through it on the GPU.

@@ -383,6 +383,8 @@ struct Block {
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
     double *gdiag = nullptr;
     int *diag_row = nullptr;  // Max-Cut-type cone: row of constraint i ...
+    int rc_w = 0;             // Max-Cut-type cone: constraints per row, fixed width (k_eval_diag; 0: a row holds too many)
+    int *rc_con = nullptr;    // [n * rc_w] row -> constraint (-1 = none)
     double *diag_a = nullptr; // ... and its coefficient (the cone then keeps w_uv = row dots U_p . V_p and w_op = p_p . V_p, n each)
     bool use_cw = false;      // operator = k_cw (constraint values from the factors) + k_spmm<CW> (slot coefficient a w_i)
     int *cadj_ptr = nullptr, *cadj_col = nullptr, *cadj_con = nullptr; // row -> (neighbour, compact constraint, a)
@@ -471,6 +473,8 @@ struct lorads_hip_ctx {
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
+    bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
+    bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
     bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
     bool avg_folded = false;  // ... and has done so for the evaluation that is enqueued next
     bool opt_front_cw = true; // k_front_cw + k_wsum instead of k_sval + k_spmm2<FRONT> + iteration 0's k_cw (LORADS_FRONT_CW=0: the latter)
@@ -579,6 +583,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
     c->opt_fold_avg = !(getenv("LORADS_FOLD_AVG") && getenv("LORADS_FOLD_AVG")[0] == '0');
+    c->opt_eval_diag = !(getenv("LORADS_EVAL_DIAG") && getenv("LORADS_EVAL_DIAG")[0] == '0');
+    c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
@@ -611,7 +617,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.rc_con); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
         hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
@@ -1209,6 +1215,19 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             else LAUNCH((k_spmm_ell<8, true, 3, 16>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col, B.cell_con,
                         B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
             break;
+        case 30: case 31: { // the one-kernel front (31: without the second visit of the slots), weights of a plain W_ADMM front
+            if (!B.front_cw) return fail_msg("ubench: cone without the one-kernel front's data");
+            FrontCwArgs A{};
+            A.fc_ptr = B.fc_ptr; A.fc_col = B.fc_col; A.fc_val = B.fc_val; A.sl_ptr = B.cadj_ptr; A.sl_col = B.cadj_col; A.sl_con = B.cadj_con;
+            A.sl_a = B.cadj_a; A.ell_col = B.cell_col; A.ell_con = B.cell_con; A.ell_a = B.cell_a; A.ell_dst = B.cell_dst; A.sl_dst = B.cadj_dst;
+            A.csum = c->csum; A.b = c->b; A.lambda = c->lambda; A.cv = B.cv; A.w_uv = B.w_op;
+            A.row_idx = B.row_idx_identity ? nullptr : B.row_idx; A.rho = 1.0; A.wmode = W_ADMM;
+            A.contrib = which == 30 ? B.w_contrib : (double *)nullptr;
+            if (B.cell_w == 8) LAUNCH((k_front_cw<3, 8>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
+            else LAUNCH((k_front_cw<3, 16>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
+        } break;
+        case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0.0,
+                        (const int *)nullptr, (const double *)c->b, (const double *)c->csum, c->lambda); break;
         case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
                        (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
         case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)B.pu.S2, V,

@@ -24,7 +24,7 @@ for name, params in [("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2)), ("rand120"
         s.solve()
         ref = s.results()
     s = common.hip_session(common.instance_path(name), world=1, rank=0, **params)
-    mode = bench.install_allreduce(s, dist, torch, device, 1, 0, "nccl")
+    mode, _seen = bench.install_allreduce(s, dist, torch, device, 1, 0, "nccl")
     s.solve()
     got = s.results()
     nat = getattr(s, "_rccl_native", None)

@@ -12,6 +12,8 @@ from lorads_amd import host  # noqa: E402
 NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>", 2: "k_spmm_ell (fixed-width slot list)",
          3: "k_spmm<CW> (CSR slot list)", 4: "k_spmm2<FRONT> (rhs + initial residual)", 5: "k_spmm2 (rhs only)",
          6: "k_cg_update 2048 wg", 7: "k_cg_update 1024 wg", 8: "k_cg_update 512 wg", 9: "k_cg_update 256 wg",
+         30: "k_front_cw (rhs + initial residual + slot contributions)", 31: "k_front_cw without the second visit of the slots",
+         32: "k_wsum (constraint weights from the contributions)",
          10: "k_obj", 11: "k_sval (two images)", 13: "k_obj, up to 2048 workgroups", 14: "k_obj, up to 4096 workgroups",
          20: "gather probe: 2.56 M random 320-B rows of V (6.4 MB table)", 21: "gather probe: rows of x and V in turn (12.8 MB)",
          22: "gather probe: the same number of rows in ascending order",
