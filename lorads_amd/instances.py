@@ -145,6 +145,28 @@ def randsparse(n, m, seed, c_edges=None, n_diag=2, n_off=8, r0=5, dense_c=False)
     return dict(m=m, blocks=[n], b=b, entries=ent)
 
 
+def with_dense_constraints(prob, n_dense, seed, r0=2):
+    """appends n_dense constraints whose A_i is a DENSE symmetric matrix (every entry non-zero, N(0,1)/n): the reference stores
+    such a coefficient packed (sdp_coeff_dense: nnz > 0.1 n(n+1)/2, data/lorads_sdp_data.c:811-828) and runs its dense
+    kernels on it (:554-567, :698-732, dense LORADSUVt lorads_alg_common.c:50-67).  b_i = <A_i, R0 R0^T> keeps the problem
+    feasible-ish (R0 drawn here; the solver converges to whatever the augmented problem's optimum is)."""
+    (n,) = prob["blocks"]
+    rng = np.random.default_rng(seed)
+    R0 = rng.standard_normal((n, r0)) / math.sqrt(n)
+    X0 = R0 @ R0.T
+    ent = list(prob["entries"])
+    b = list(prob["b"])
+    m0 = prob["m"]
+    for k in range(n_dense):
+        g = rng.standard_normal((n, n)) / n
+        a = (g + g.T) / 2
+        for i in range(n):
+            for j in range(i, n):
+                ent.append((m0 + k + 1, 1, i + 1, j + 1, float(a[i, j])))
+        b.append(float(np.sum(a * X0)))
+    return dict(m=m0 + n_dense, blocks=[n], b=np.array(b), entries=ent)
+
+
 def blockdiag_maxcut(nblk, n_k, edges_k, seed0):
     """cfg4: nblk independent max-cut blocks, block-separable constraints, m = nblk * n_k."""
     ent = []
@@ -289,6 +311,8 @@ NAMED = {
     "coupled3x70": lambda: coupled_blocks(3, 70, 30, 3100, n_diag=1, n_off=2, r0=2, c_edges=60),
     "densec40": lambda: randsparse(40, 20, 777, n_diag=1, n_off=2, r0=2, dense_c=True),
     "matcomp60": lambda: matcomp(30, 30, 200, 3, 50),
+    # three DENSE constraint matrices next to sparse ones: the reference's dense-coefficient kernels (sdp_coeff_dense)
+    "densea40": lambda: with_dense_constraints(randsparse(40, 17, 781, c_edges=60, n_diag=1, n_off=2, r0=2), 3, 782),
     # separable cones of different size and kind, equal rank 9: the lockstep (batched) sweep with row padding
     "mix4": lambda: block_diag([maxcut(60, 90, 61), randsparse(70, 45, 62, c_edges=90, n_diag=2, n_off=3, r0=3),
                                 maxcut(66, 100, 63), matcomp(35, 33, 220, 3, 64)]),

@@ -36,6 +36,7 @@ TRACE = {
     "coupled3x70": (8, 3, ["--phase1Tol", "1e-2"]),
     "densec40": (8, 3, ["--phase1Tol", "1e-2"]),
     "matcomp60": (8, 3, ["--phase1Tol", "1e-2"]),
+    "densea40": (8, 3, ["--phase1Tol", "1e-2"]),
     "mix4": (8, 3, ["--phase1Tol", "1e-2"]),
     "sdplp40": (8, 3, ["--phase1Tol", "1e-2"]),
     "sdpslack30": (8, 3, ["--phase1Tol", "1e-2"]),
@@ -52,6 +53,7 @@ SOLVE = [
     ("coupled3x70", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("densec40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("matcomp60", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
+    ("densea40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("mix4", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("sdplp40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),
     ("sdplp40", ["--reoptLevel", "0"]),

@@ -50,6 +50,10 @@ elif "k_cw" in ks and "k_spmm_ell" in ks:
     out["cg_operator_application"] = {"kernels": ["k_cw", "k_spmm_ell"], "traffic_bytes": op}
     if "k_spmm2" in ks:  # front of a solve (right-hand side + initial residual in one pass)
         out["solve_front"] = {"kernels": ["k_spmm2"], "traffic_bytes": ks["k_spmm2"]["read_bytes_median"] + ks["k_spmm2"]["write_bytes_mean"]}
+    if "k_front_cw" in ks:  # the one-kernel front (+ k_wsum: iteration 0's constraint weights)
+        out["solve_front"] = {"kernels": ["k_front_cw"], "traffic_bytes": ks["k_front_cw"]["read_bytes_median"] + ks["k_front_cw"]["write_bytes_mean"]}
+        if "k_wsum" in ks:
+            out["iteration0_weights"] = {"kernels": ["k_wsum"], "traffic_bytes": ks["k_wsum"]["read_bytes_median"] + ks["k_wsum"]["write_bytes_mean"]}
 elif "k_cw" in ks and "k_spmm" in ks:
     # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm<CW> CSR form (the more frequent k_spmm
     # population -> median)

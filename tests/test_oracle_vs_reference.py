@@ -5,7 +5,7 @@ import pytest
 
 from tests import common
 
-TRACE_NAMES = ["maxcut100", "theta30", "rand120", "blk4x60", "coupled3x70", "densec40", "matcomp60", "mix4", "sdplp40", "sdpslack30", "coupledlp"]
+TRACE_NAMES = ["maxcut100", "theta30", "rand120", "blk4x60", "coupled3x70", "densec40", "densea40", "matcomp60", "mix4", "sdplp40", "sdpslack30", "coupledlp"]
 
 
 @pytest.mark.parametrize("name", TRACE_NAMES)
