@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-rnd = sys.argv[1]
-out = os.path.join(ROOT, "profiles" if len(sys.argv) < 3 else sys.argv[2], "%s_stamp.json" % rnd)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+rnd = args[0]
+out = os.path.join(ROOT, "profiles" if len(args) < 2 else args[1], "%s_stamp.json" % rnd)
 st = {}
 if os.path.exists(out):
     with open(out) as fh:
