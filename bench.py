@@ -412,6 +412,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             replicate_blocks(base, world, path)
         dist.barrier()
 
+    t_setup0 = time.time()
     s = host.Session.open(path)
     s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
     if workload == "matcomp50000" and os.environ.get("LORADS_BENCH_RANK_GROWTH") != "1":
@@ -419,7 +420,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         # ADMM iterations start (LORADS_BENCH_RANK_GROWTH=1: let it)
         s.set_params(dyrankLevel=0)
     s.prepare(world, rank)   # cones dealt round-robin over the ranks
+    t_setup1 = time.time()
     s.attach_hip()
+    t_setup2 = time.time()
     ar_mode, ranks_seen = None, 1
     if dist:
         ar_mode, ranks_seen = install_allreduce(s, dist, torch, device, world, rank, os.environ.get("LORADS_DIST_BACKEND", "nccl"))
@@ -562,6 +565,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
                                        % ("cones dealt over the ranks" if strong else "block-per-GPU", ar_mode)) if world > 1 else "single GPU",
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (tlr, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
+            # start-up cost, untimed: reader + host pre-solve (rank rule, start point), then the device image
+            # (patterns, adjacency, slot lists, uploads) built inside lorads_hip_create
+            "setup_seconds": {"read_and_presolve_host": t_setup1 - t_setup0, "device_image_in_create": t_setup2 - t_setup1},
             "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x): %s" % op_kernels,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
