@@ -378,6 +378,7 @@ struct Block {
     double *Wd = nullptr;     // n x r result of C X
     double *Wpart = nullptr;  // split-K slabs of it
     int ksplit = 1;
+    int ksplit_b = 0;         // K split over workgroups of the second dense form (k_dense_cx_b; 0: not applicable)
     bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
@@ -473,6 +474,7 @@ struct lorads_hip_ctx {
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
+    bool opt_dense_b = true;  // dense objective: C read as the MFMA B operand (k_dense_cx_b; LORADS_DENSE_B=0: k_dense_cx)
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
     bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
     bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
@@ -585,6 +587,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_fold_avg = !(getenv("LORADS_FOLD_AVG") && getenv("LORADS_FOLD_AVG")[0] == '0');
     c->opt_eval_diag = !(getenv("LORADS_EVAL_DIAG") && getenv("LORADS_EVAL_DIAG")[0] == '0');
     c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
+    c->opt_dense_b = !(getenv("LORADS_DENSE_B") && getenv("LORADS_DENSE_B")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
