@@ -1076,8 +1076,8 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
         for (int k = 0; k < c->nb; ++k) {
             Block &B = c->blk[k];
             if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
-            if (B.dense_c && nr[k] > 128)
-                return fail_msg("resize_rank: a cone with a dense objective matrix supports rank <= 128 (MFMA tile kernel)");
+            if (B.dense_c && nr[k] > 128 && B.ksplit_b == 0)
+                return fail_msg("resize_rank: this cone's dense objective kernel supports rank <= 128");
             if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > MAXPART)
                 return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
             std::vector<double> oldm((size_t)B.n * B.r);

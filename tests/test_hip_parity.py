@@ -443,12 +443,12 @@ def test_lockstep_sweep_equals_cone_by_cone(built, name, grow):
                                         ("maxcut100", [1, 5, 40, 65, 128, 131, 258]),
                                         ("matcomp60", [1, 4, 30, 67, 140]),
                                         ("blk4x60", [1, 6, 31, 70, 133]),
-                                        ("densec40", [1, 2, 17, 48, 127, 128])])
+                                        ("densec40", [1, 2, 17, 48, 127, 128, 129, 144, 200, 258])])
 def test_every_rank_shape_vs_oracle(built, name, ranks):
     """The row kernels are instantiated per (lanes per row, 16-byte loads, column steps): r even <= 128 -> 8 lanes x
     double2, odd or larger r -> 8 / 32 / 64 lanes x double.  Every shape, on the general (Gram), diagonal, single-entry,
-    merged multi-cone and dense-C (MFMA, r <= 128) operator paths, function by function against the oracle from the
-    same random factors."""
+    merged multi-cone and dense-C (MFMA; ranks above 128 take several launches of eight column tiles) operator paths, function
+    by function against the oracle from the same random factors."""
     path = common.instance_path(name)
     for r in ranks:
         # the rank rule gives ceil(timesLogRank * ln n) (capped): aim at r from below, grow to r if the cap bites
