@@ -963,7 +963,8 @@ int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxi
 
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
     c->ls_np = 0;
-    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && !c->ar) { // (see pend_dual)
+    // (see pend_dual; with sharded cones only the one-kernel front can take it: it needs no owner pairs, k_wsum stores all of lambda)
+    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && (!c->ar || front_cw_ok(c, c->blk[0]))) {
         flush_pending(c);
         c->pend_dual = true;
         c->pend_dual_rho = rho;
@@ -1230,7 +1231,7 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             else LAUNCH((k_front_cw<3, 16>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
         } break;
         case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0.0,
-                        (const int *)nullptr, (const double *)c->b, (const double *)c->csum, c->lambda); break;
+                        c->m, (const double *)c->b, (const double *)c->csum, c->lambda); break;
         case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
                        (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
         case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)B.pu.S2, V,
