@@ -379,6 +379,16 @@ struct Block {
     double *Wpart = nullptr;  // split-K slabs of it
     int ksplit = 1;
     int ksplit_b = 0;         // K split over workgroups of the second dense form (k_dense_cx_b; 0: not applicable)
+    // DENSE constraint matrices (the reference's sdp_coeff_dense rule, data/lorads_sdp_data.c:820: nnz > 0.1 n(n+1)/2): kept
+    // out of the sparse patterns (their rows of the constraint CSR are empty there) and stored as full symmetric npad x npad
+    // matrices; their part of every A / A^* runs through the dense GEMM (k_dense_cx_b) -- see dense_constr_fix / dense_part
+    bool dense_a = false;
+    int nd = 0;               // how many
+    int *d_con = nullptr;     // [nd] local constraint index
+    std::vector<int> d_con_h; // (host copy)
+    double *Adense = nullptr; // [nd][npad * npad]
+    double *Sfull = nullptr;  // npad * npad scratch: [C +] sum_j mu_j A_j
+    double *d_mu = nullptr;   // [nd] the weights of the current combination
     bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
@@ -621,7 +631,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.rc_con); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
-        hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
+        hipFree(B.d_con); hipFree(B.Adense); hipFree(B.Sfull); hipFree(B.d_mu); hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
         hipFree(B.g_val);
@@ -688,9 +698,9 @@ static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
-        if (B.dense_c) dense_cx(c, B, c->R + B.off, B.Wd, NOGUARD);
+        if (B.dense_c || B.dense_a) dense_part(c, B, c->R + B.off, W_ALM, wa, 1.0, true, NOGUARD);
         int g = spmm(c, B, B.pu, c->R + B.off, OP_GRAD, nullptr, nullptr, rho, c->G + B.off, part_slot(c, 0), NOGUARD,
-                     B.dense_c ? B.Wd : nullptr);
+                     (B.dense_c || B.dense_a) ? B.Wd : nullptr);
         LAUNCH(k_finalize, 1, part_slot(c, 0), g, 1.0, 1, c->scal + 8, NOGUARD);
     }
     return allreduce_dev(c, c->scal + 8, 1);
@@ -771,7 +781,7 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
 static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
     const int m = c->m;
     Block *S1 = solo(c);
-    if (S1 && S1->nrow == m && m > 0 && !S1->dense_c && S1->nc > 0) {
+    if (S1 && S1->nrow == m && m > 0 && !S1->dense_c && !S1->dense_a && S1->nc > 0) {
         // one cone that sees every constraint: (R,D) and (D,D) share each row visit -- 4 launches
         Block &B = *S1;
         const Shape sh = shape_for(B.r);
@@ -883,7 +893,7 @@ int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double ou
 }
 int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
     Block *S1 = solo(c);
-    if (S1 && S1->nrow == c->m && c->m > 0 && !S1->dense_c) {
+    if (S1 && S1->nrow == c->m && c->m > 0 && !S1->dense_c && !S1->dense_a) {
         // one cone that sees every constraint: 7 launches for the whole second half
         Block &B = *S1;
         Ring &h = c->ring[c->head];
@@ -1284,6 +1294,7 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
     const Block &B = c->blk[k];
     *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.use_cw ? 4 : B.has_gram ? 0 : 1;
+    if (B.dense_a) *kind += 16; // + dense constraint matrices through the dense GEMM
     return 0;
 }
 

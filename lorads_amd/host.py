@@ -403,7 +403,8 @@ class Session:
         lib, ctx = self._hip()
         k = C.c_int()
         _check(lib.lorads_hip_operator_kind(ctx, blk, C.byref(k)), "operator_kind")
-        return ["k_pairdots+k_sgram+k_spmm2", "k_pairdots+k_cv+k_sval+k_spmm2", "k_op_diag", "k_op_entry", "k_cw+k_spmm_ell"][k.value]
+        base = ["k_pairdots+k_sgram+k_spmm2", "k_pairdots+k_cv+k_sval+k_spmm2", "k_op_diag", "k_op_entry", "k_cw+k_spmm_ell"][k.value & 15]
+        return base + ("+k_dense_cx_b(dense A_i)" if k.value & 16 else "")
 
     def hip_stream(self):
         """hipStream_t of the library as an integer (torch.cuda.ExternalStream takes it)"""

@@ -317,6 +317,8 @@ NAMED = {
     "mix4": lambda: block_diag([maxcut(60, 90, 61), randsparse(70, 45, 62, c_edges=90, n_diag=2, n_off=3, r0=3),
                                 maxcut(66, 100, 63), matcomp(35, 33, 220, 3, 64)]),
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
+    "densea300": lambda: with_dense_constraints(randsparse(300, 60, 783, c_edges=900, n_diag=2, n_off=4, r0=3), 4, 784),  # dense A_i -> MFMA path
+    "denseac200": lambda: with_dense_constraints(randsparse(200, 40, 785, n_diag=2, n_off=4, r0=3, dense_c=True), 3, 786),  # dense C AND dense A_i
     # SDP cone + LP block (slacks and coupling columns): the LP path (closed-form column sweep)
     "sdplp40": lambda: sdp_lp(40, 90, 12, 4001),
     "sdpslack30": lambda: sdp_lp(30, 60, 0, 4002),

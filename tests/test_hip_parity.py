@@ -44,12 +44,14 @@ def _gen(name):
 
 
 @pytest.mark.parametrize("name,tlr", [("maxcut800", 2.0), ("maxcut4000", 3.0), ("rand4000", 3.0), ("densec300", 2.0),
-                                      ("densec300", 7.0)])
+                                      ("densec300", 7.0), ("densea300", 2.0), ("densea300", 6.5), ("denseac200", 3.0)])
 def test_functions_vs_oracle_midsize(built, name, tlr):
     """same seeded input through both tables, function by function (sizes the oracle finishes in seconds)"""
     path = common.instance_path(name) if name == "maxcut800" else _gen(name)
     hs, os_ = _pair(path, timesLogRank=tlr)
     try:
+        if name.startswith("densea"):   # the dense constraint matrices really take the dense GEMM
+            assert "k_dense_cx_b(dense A_i)" in hs.hip_operator_kind(0)
         rho = 0.5
         for it in range(3):
             vals = []

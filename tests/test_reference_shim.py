@@ -61,6 +61,7 @@ def _golden(instance, flags):
     ("sdplp40", ["--reoptLevel", "0"]),                                     # SDP cone + LP block
     ("rand120", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),   # reopt round: objScale_dualvar, ALM_reopt, ADMM_reopt
     ("mix4", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),      # rank growth (AUG_RANK) inside the reference's loop
+    ("densea40", ["--reoptLevel", "1", "--phase1Tol", "1e-2", "--phase2Tol", "1e-7"]),  # sdp_coeff_dense constraints flattened; MFMA path
 ])
 def test_reference_loops_drive_the_hip_library(built, instance, flags):
     _need_shim()
