@@ -23,6 +23,12 @@ def test_abi_library_exports_every_declared_symbol(built):
     lib = C.CDLL(os.path.join(host.LIB_DIR, "liblorads_hip.so"))
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
+    # the measurement / diagnostic entries live in their own header and are exported too; the drop-in header has none of them
+    dev = open(os.path.join(ROOT, "include", "lorads_hip_dev.h")).read()
+    dev_syms = sorted(set(re.findall(r"\b(lorads_hip_[a-z0-9_]+)\s*\(", dev)))
+    assert {"lorads_hip_profile", "lorads_hip_profile_samples", "lorads_hip_ubench", "lorads_hip_operator_kind"} <= set(dev_syms)
+    assert not [s for s in dev_syms if not hasattr(lib, s)]
+    assert not (set(dev_syms) & set(declared)), "measurement entries leaked into the product header"
 
 
 def test_rccl_hook_library_exports_every_declared_symbol(built):
