@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02p10; mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 bench.py --workload blk16x4000 --times-log-rank 2.0 --no-cpu --no-extra --steps 50 --warmup 5 --windows 1 --roofline-samples 0 > $O/kt.log 2>&1
+T=$(ls $O/kt/*kernel_trace.csv | head -1); python profiles/trace_summary.py $T > $O/blk16x4000_admm_summary.txt; rm -f $T; head -14 $O/blk16x4000_admm_summary.txt; tail -2 $O/blk16x4000_admm_summary.txt
