@@ -44,6 +44,9 @@ ks = out["kernels"]
 if "k_op_diag" in ks:
     op = ks["k_op_diag"]["read_bytes_median"] + ks["k_op_diag"]["write_bytes_mean"]
     out["cg_operator_application"] = {"kernels": ["k_op_diag"], "traffic_bytes": op}
+elif "k_op_entry" in ks:
+    op = ks["k_op_entry"]["read_bytes_median"] + ks["k_op_entry"]["write_bytes_mean"]
+    out["cg_operator_application"] = {"kernels": ["k_op_entry"], "traffic_bytes": op}
 elif "k_cw" in ks and "k_spmm_ell" in ks:
     # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm_ell (fixed-width slot list)
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_cw", "k_spmm_ell"))
@@ -64,4 +67,4 @@ elif "k_spmm" in ks:
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_pairdots", "k_sgram", "k_spmm") if k in ks)
     out["cg_operator_application"] = {"kernels": [k for k in ("k_pairdots", "k_sgram", "k_spmm") if k in ks], "traffic_bytes": op}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["cg_operator_application"]))
+print(json.dumps(out.get("cg_operator_application")))
