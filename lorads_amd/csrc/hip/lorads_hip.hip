@@ -485,6 +485,7 @@ struct lorads_hip_ctx {
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
+    bool opt_dense_rem = true; // dense GEMM: 1..4 columns beyond the full tiles on plain FMAs instead of a tile of their own (LORADS_DENSE_REM=0)
     bool opt_dense_b = true;  // dense objective: C read as the MFMA B operand (k_dense_cx_b; LORADS_DENSE_B=0: k_dense_cx)
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
     bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
@@ -600,6 +601,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
     c->opt_dense_b = !(getenv("LORADS_DENSE_B") && getenv("LORADS_DENSE_B")[0] == '0');
     c->opt_fuse_eval = !(getenv("LORADS_FUSE_EVAL") && getenv("LORADS_FUSE_EVAL")[0] == '0');
+    c->opt_dense_rem = !(getenv("LORADS_DENSE_REM") && getenv("LORADS_DENSE_REM")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
     c->opt_split_front = getenv("LORADS_SPLIT_FRONT") && getenv("LORADS_SPLIT_FRONT")[0] == '1';
     c->scal = (double *)c->ctrl;
