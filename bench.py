@@ -419,7 +419,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         # BASELINE cfg5 names r = 60: with the default rank-growth rule phase 1 takes this instance to r = 90 before the timed
         # ADMM iterations start (LORADS_BENCH_RANK_GROWTH=1: let it)
         s.set_params(dyrankLevel=0)
-    s.prepare(world, rank)   # cones dealt round-robin over the ranks
+    # cones dealt round-robin over the ranks; a block-separable deal (both workloads here) leaves each rank the sub-problem over
+    # its own constraints, and the ranks share four scalars per ADMM iteration instead of the m-vector (LORADS_SEPARABLE=0: that)
+    s.prepare(world, rank, separable=world > 1 and os.environ.get("LORADS_SEPARABLE", "1") != "0")
     t_setup1 = time.time()
     s.attach_hip()
     t_setup2 = time.time()

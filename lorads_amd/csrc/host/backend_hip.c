@@ -150,6 +150,16 @@ int lrd_hip_backend_create(const lrd_problem *p, int lbfgs_len, const char *libp
         free(h);
         return 12;
     }
+    if (p->separable) { /* this image is one rank's sub-problem of a block-separable deal: only scalars cross the ranks */
+        int (*set_sep)(lorads_hip_ctx *, int32_t);
+        *(void **)(&set_sep) = dlsym(h->dl, "lorads_hip_set_separable");
+        if (!set_sep || set_sep(h->ctx, 1)) {
+            fprintf(stderr, "lorads: %s cannot take a separable shard (lorads_hip_set_separable)\n", libpath);
+            h->destroy(h->ctx);
+            free(h);
+            return 13;
+        }
+    }
     memset(out, 0, sizeof *out);
     out->ctx = h;
     out->name = "hip-gfx950";

@@ -83,6 +83,10 @@ typedef struct {
     int sum_dims_global; /* sum of all SDP block dims, for rho0 = 1/sqrt(.) (data/lorads_solver.c:1155-1162) */
     /* norms (data/lorads_solver.c:1054-1073), over ALL blocks of the file */
     double cObjNrm1, cObjNrm2, cObjNrmInf, bNrm1, bNrm2, bNrmInf;
+    /* set by lrd_problem_localize: this image is one rank's sub-problem of a block-separable deal -- m, b and the row indices are
+     * the rank's own; con_global[i] = index of local constraint i in the file (m_global constraints) */
+    int separable, m_global;
+    int *con_global;
 } lrd_problem;
 
 /* which factor pair an evaluation uses */
@@ -204,6 +208,7 @@ int lrd_problem_from_triplets(int m, const double *b, int nblk, const int *dims,
                               lrd_problem **out);
 /* multi-GPU sharding: keep only the blocks with keep[k] != 0 (global consts stay global) */
 void lrd_problem_select(lrd_problem *p, const int *keep);
+int lrd_problem_localize(lrd_problem *p, int world, int rank_id);
 void lrd_problem_free(lrd_problem *p);
 /* rank rule, data/lorads_solver.c:290-319 */
 void lrd_determine_rank(lrd_problem *p, double times_log_rank);

@@ -65,6 +65,7 @@ void lrd_problem_free(lrd_problem *p) {
     for (int k = 0; k < p->nblk; ++k) block_free(&p->blk[k]);
     free(p->blk);
     free(p->b);
+    free(p->con_global);
     free(p);
 }
 
@@ -319,6 +320,52 @@ void lrd_problem_select(lrd_problem *p, const int *keep) {
         else block_free(&p->blk[k]);
     }
     p->nblk = w;
+}
+
+/* Sharded cones whose constraints are block-separable over the ranks (no constraint touches cones of two ranks; cone k lives on
+ * rank k % world): every m-vector of the method -- constrValSum, lambda, q1, q2 -- then splits into per-rank pieces nobody else
+ * reads, and the ranks only share SCALARS.  keep[] = the cones of this rank.  Returns 1 and rewrites the image into the rank's own
+ * sub-problem (its constraints renumbered 0..m_local-1 in ascending global order, b cut to them, row indices remapped; a constraint
+ * no cone touches goes to rank 0; the norms stay those of the whole problem) when the deal is separable; returns 0 and leaves
+ * the image alone when some constraint is shared.  Call BEFORE lrd_problem_select (it looks at every cone of the file). */
+int lrd_problem_localize(lrd_problem *p, int world, int rank_id) {
+    const int m = p->m;
+    int *owner = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    for (int i = 0; i < m; ++i) owner[i] = -1;
+    int shared = 0;
+    for (int k = 0; k < p->nblk && !shared; ++k) {
+        const lrd_block *b = &p->blk[k];
+        const int rk = k % world;
+        for (int t = 0; t < b->nrow; ++t) {
+            const int i = b->row_idx[t];
+            if (owner[i] >= 0 && owner[i] != rk) { shared = 1; break; }
+            owner[i] = rk;
+        }
+    }
+    if (shared) { free(owner); return 0; }
+    int *loc = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    int ml = 0;
+    for (int i = 0; i < m; ++i) {
+        const int o = owner[i] < 0 ? 0 : owner[i];
+        loc[i] = o == rank_id ? ml++ : -1;
+    }
+    int *glob = (int *)malloc(sizeof(int) * (size_t)(ml > 0 ? ml : 1));
+    double *bl = (double *)malloc(sizeof(double) * (size_t)(ml > 0 ? ml : 1));
+    for (int i = 0; i < m; ++i)
+        if (loc[i] >= 0) { glob[loc[i]] = i; bl[loc[i]] = p->b[i]; }
+    for (int k = 0; k < p->nblk; ++k) {
+        if (k % world != rank_id) continue;
+        lrd_block *b = &p->blk[k];
+        for (int t = 0; t < b->nrow; ++t) b->row_idx[t] = loc[b->row_idx[t]]; /* (ascending order is kept) */
+    }
+    free(p->b);
+    p->b = bl;
+    p->m_global = m;
+    p->m = ml;
+    p->con_global = glob;
+    p->separable = 1;
+    free(owner); free(loc);
+    return 1;
 }
 
 void lrd_determine_rank(lrd_problem *p, double times) {

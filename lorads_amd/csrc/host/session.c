@@ -57,12 +57,15 @@ lrd_problem *lrd_session_problem(lrd_session *s) { return s->prob; }
 lrd_solver *lrd_session_solver(lrd_session *s) { return s->have_sol ? &s->sol : NULL; }
 lrd_backend *lrd_session_backend(lrd_session *s) { return s->have_be ? &s->be : NULL; }
 
-/* rank rule + start point + (optional) round-robin sharding of blocks over `world` processes */
-int lrd_session_prepare(lrd_session *s, int world, int rank_id) {
+/* rank rule + start point + (optional) round-robin sharding of blocks over `world` processes.
+ * allow_separable: the backend can work on a rank's own sub-problem and share only scalars (the HIP library:
+ * lorads_hip_set_separable) -- then a block-separable deal is cut down to this rank's constraints (lrd_problem_localize) */
+int lrd_session_prepare_sharded(lrd_session *s, int world, int rank_id, int allow_separable) {
     lrd_determine_rank(s->prob, s->par.timesLogRank);
     double **R, **U, **V;
     lrd_init_point(s->prob, &R, &U, &V);
     int nb = s->prob->nblk;
+    if (world > 1 && allow_separable) lrd_problem_localize(s->prob, world, rank_id);
     if (world > 1) {
         int *keep = (int *)calloc((size_t)nb, sizeof(int));
         int w = 0;
@@ -86,6 +89,16 @@ int lrd_session_block_info(lrd_session *s, int k, int *n, int *rank, int *nrow, 
     *n = b->n; *rank = b->rank; *nrow = b->nrow; *na = b->a_ptr[b->nrow]; *nc = b->c_nnz; *np = b->np;
     *dense_mode = b->dense_mode; *cone_sparse = b->cone_sparse;
     return 0;
+}
+int lrd_session_prepare(lrd_session *s, int world, int rank_id) { return lrd_session_prepare_sharded(s, world, rank_id, 0); }
+/* separable deal (see lrd_session_prepare_sharded)?  m_global = constraints of the file; map[i] (m entries, may be NULL) = index of
+ * local constraint i in the file */
+int lrd_session_separable(lrd_session *s, int *m_global, int *map) {
+    const lrd_problem *p = s->prob;
+    if (!p->separable) { if (m_global) *m_global = p->m; return 0; }
+    if (m_global) *m_global = p->m_global;
+    if (map) memcpy(map, p->con_global, sizeof(int) * (size_t)p->m);
+    return 1;
 }
 int lrd_session_dims(lrd_session *s, int *m, int *nblk, int *nblk_global) {
     *m = s->prob->m; *nblk = s->prob->nblk; *nblk_global = s->prob->nblk_global;

@@ -291,11 +291,22 @@ class Session:
             if self.lib.lrd_session_set_param(self.h, k.encode(), txt.encode()):
                 raise KeyError("unknown parameter %s" % k)
 
-    def prepare(self, world=1, rank=0):
-        _check(self.lib.lrd_session_prepare(self.h, world, rank), "prepare")
+    def prepare(self, world=1, rank=0, separable=False):
+        """separable=True (HIP backend only): when no constraint touches cones of two ranks, this process keeps the sub-problem
+        over its own constraints (m, b, row indices local) and the library shares only scalars with the other ranks
+        (lorads_hip_set_separable); self.separable tells whether the deal was, self.constraint_map[i] = index of local
+        constraint i in the file, self.m_global = constraints of the file."""
+        self.lib.lrd_session_prepare_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _check(self.lib.lrd_session_prepare_sharded(self.h, world, rank, int(bool(separable))), "prepare")
         m, nb, nbg = C.c_int(), C.c_int(), C.c_int()
         self.lib.lrd_session_dims(self.h, C.byref(m), C.byref(nb), C.byref(nbg))
         self.m, self.nblk, self.nblk_global = m.value, nb.value, nbg.value
+        mg = C.c_int()
+        cmap = np.zeros(max(self.m, 1), dtype=np.int32)
+        self.lib.lrd_session_separable.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.separable = bool(self.lib.lrd_session_separable(self.h, C.byref(mg), cmap.ctypes.data_as(C.POINTER(C.c_int))))
+        self.m_global = mg.value
+        self.constraint_map = cmap[:self.m] if self.separable else np.arange(self.m, dtype=np.int32)
 
     def block_info(self, k):
         v = [C.c_int() for _ in range(8)]

@@ -120,6 +120,47 @@ def test_rank_rule_and_branches(tmp_path, oracle_lib):
             s.close()
 
 
+def test_separable_deal_is_cut_down_to_the_ranks_own_constraints(oracle_lib):
+    """lrd_problem_localize: blk4x60 (every constraint lives in one cone) dealt over 2 and 4 ranks leaves each rank the
+    sub-problem over its own constraints -- a partition of the file's constraints, b and the norms of the whole problem kept;
+    coupled3x70 (constraints that touch several cones) is left alone."""
+    full = host.Session.open(common.instance_path("blk4x60"), lib=oracle_lib)
+    full.set_params(verbose=0)
+    full.prepare()
+    m_all, rows_all = full.m, [full.block_info(k)["nrow"] for k in range(full.nblk)]
+    full.close()
+    for world in (2, 4):
+        seen = []
+        for rank in range(world):
+            s = host.Session.open(common.instance_path("blk4x60"), lib=oracle_lib)
+            try:
+                s.set_params(verbose=0)
+                s.prepare(world, rank, separable=True)
+                assert s.separable and s.m_global == m_all and s.nblk == 4 // world
+                assert s.m == sum(rows_all[k] for k in range(4) if k % world == rank)
+                cm = s.constraint_map
+                assert len(cm) == s.m and np.all(np.diff(cm) > 0)      # ascending file order
+                seen.append(cm.copy())
+            finally:
+                s.close()
+        allc = np.sort(np.concatenate(seen))
+        assert np.array_equal(allc, np.arange(m_all))                   # a partition
+    s = host.Session.open(common.instance_path("coupled3x70"), lib=oracle_lib)
+    try:
+        s.set_params(verbose=0)
+        s.prepare(2, 0, separable=True)
+        assert not s.separable and s.m == s.m_global
+    finally:
+        s.close()
+    s = host.Session.open(common.instance_path("blk4x60"), lib=oracle_lib)
+    try:
+        s.set_params(verbose=0)
+        s.prepare(2, 1)                                                 # not asked for: the general sharded form
+        assert not s.separable and s.m == m_all
+    finally:
+        s.close()
+
+
 def test_cubic_and_linesearch_scalars(oracle_lib):
     lib = oracle_lib
     lib.lrd_cubic_roots.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)]
