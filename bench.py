@@ -8,7 +8,9 @@ Workload (BASELINE.json configs[2]): one dense-cone block n 
 (--timesLogRank 4.0), m = 5000 random sparse A_i (2 diagonal + 8 off-diagonal entries each),
 C = L/4 + I/4 of a 120000-edge random graph, b = A(R0 R0^T); generated with fixed seeds by
 lorads_amd/instances.py.  N GPUs = N such blocks (block-diagonal SDP, block-separable constraints),
-one block per GPU, ONE all-reduce of the shared m-vector per ADMM iteration (weak scaling).
+one block per GPU; the deal is block-separable, so every rank works on the sub-problem over its own constraints and ONE
+all-reduce of four scalars per ADMM iteration is all the ranks share (weak scaling; LORADS_SEPARABLE=0: the general form, one
+all-reduce of the shared m-vector).
 
 A step = one ADMM iteration = admmUpdateVar (U- and V-solve by CG) + objective + dual objective +
 DIMACS refresh + dual update (reference lorads_admm.c:76-81,120), with rho fixed at its hand-off
@@ -563,8 +565,11 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             "cg_iters_per_admm_iter": cg_iters / units,
             "config": {"workload": cfg_txt,
                        "n": info["n"], "r": info["rank"], "r_at_start": r_start, "m_per_block": info["nrow"], "blocks": s.nblk_global,
-                       "parallelism": ("%s, 1 all-reduce of the shared m-vector per ADMM iteration (%s)"
-                                       % ("cones dealt over the ranks" if strong else "block-per-GPU", ar_mode)) if world > 1 else "single GPU",
+                       "parallelism": ("%s, 1 all-reduce of %s per ADMM iteration (%s)"
+                                       % ("cones dealt over the ranks" if strong else "block-per-GPU",
+                                          "four scalars (separable shards: every rank holds its own constraints)" if s.separable
+                                          else "the shared m-vector", ar_mode)) if world > 1 else "single GPU",
+                       "separable_shards": bool(s.separable) if world > 1 else None,
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (tlr, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
             # start-up cost, untimed: reader + host pre-solve (rank rule, start point), then the device image

@@ -145,6 +145,13 @@ int lorads_hip_set_allreduce(lorads_hip_ctx *ctx, lorads_hip_allreduce_fn fn, vo
  * the host before calling it, so a multi-GPU ADMM iteration still has a single host sync. */
 void *lorads_hip_stream(lorads_hip_ctx *ctx);
 int lorads_hip_set_allreduce_stream_ordered(lorads_hip_ctx *ctx, int32_t on);
+/* Sharded cones whose constraints are BLOCK-SEPARABLE over the ranks (no constraint touches cones of two ranks): the caller
+ * creates each rank's context on the sub-problem over the rank's own constraints (m, b, row indices local; b_nrm1 of the
+ * whole problem) and declares it here.  Every m-vector of the method then lives on one rank only, and the library sums
+ * SCALARS over the ranks instead of constrValSum, q1, q2: per ADMM iteration one all-reduce of four doubles
+ * {||b - A(RR^T)||^2 part, b.lambda part, <C,RR^T> part, "my sweep is unfinished"}, and the rank's iteration is the
+ * single-GPU iteration (all its fused paths) around it.  lorads_hip_get_vec / set_vec move the rank's own pieces. */
+int lorads_hip_set_separable(lorads_hip_ctx *ctx, int32_t on);
 /* all-reduces constrValSum through the hook once (lets the caller validate its hook) */
 int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *ctx);
 

@@ -467,6 +467,7 @@ struct lorads_hip_ctx {
     double *Dtmp = nullptr;
     double *cstage = nullptr; // m+2 (+ objective partials): [local constrValSum | objective part | miss flag | partials] on its way through the all-reduce
     bool stage_clean = false; // cstage[0..m) is known to be zero (left so by k_commit_eval)
+    int ar_fast_all = -1;     // every rank holds one cone that can send its objective partials through the all-reduce (-1: not yet agreed)
     bool opt_ar_fast = true;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
     double *part = nullptr;   // NSLOT x MAXPART partial sums
@@ -517,6 +518,11 @@ struct lorads_hip_ctx {
     lorads_hip_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
     bool ar_stream_ordered = false; // the hook enqueues on our stream (RCCL): no host sync around it
+    bool sep = false; // lorads_hip_set_separable: this context holds one rank's own constraints; only scalars cross the ranks
+    double *sepbuf = nullptr; // 32: scalars on their way through the all-reduce in that mode
+    SepExtra sep_extra{};     // scalars the next evaluation's all-reduce also carries (set by the caller, taken by enqueue_eval)
+    double *gram = nullptr;   // 128: [0..66) products V_a.V_b of the Gram-form L-BFGS direction, [80..91) the coefficients of D
+    bool opt_gram = true;     // LORADS_LBFGS_GRAM=0: sharded direction by the sequential recursion, one collective per dot
     // profiling
     int prof = 0, prof_every = 8;
     long n_sweeps = 0;        // ADMM sweeps run so far (cadence of the exact constraint refresh, see constr_by_recurrence)
@@ -547,6 +553,9 @@ inline int lg_for(int r) { return use_v2(r) ? 8 : (r <= 64 ? 8 : (r <= 256 ? 32 
 const Guard NOGUARD{nullptr, nullptr};
 
 double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * MAXPART; }
+// sharded cones that share constraints: constrValSum, q1, q2 are summed over the ranks as m-vectors.  Separable shards
+// (lorads_hip_set_separable) hold their own constraints: only scalars are summed (c->ar && c->sep).
+inline bool shard_vec(const lorads_hip_ctx *c) { return c->ar && !c->sep; }
 
 #include "build.inc"
 #include "sweep.inc"
@@ -577,7 +586,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->lambda_alt, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
-        dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) ||
+        dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) || dalloc(&c->gram, 128) ||
         dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
         dalloc(&c->ring_ab, (size_t)2 * c->L)) {
@@ -592,6 +601,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->use_publish = !getenv("LORADS_NO_PUBLISH");
     c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
+    c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
@@ -641,7 +651,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         hipFree(B.g_val);
     }
     free_factors(c);
-    hipFree(c->cstage);
+    hipFree(c->cstage); hipFree(c->sepbuf); hipFree(c->gram);
     hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
@@ -661,6 +671,14 @@ int lorads_hip_sync(lorads_hip_ctx *c) {
 int lorads_hip_set_allreduce(lorads_hip_ctx *c, lorads_hip_allreduce_fn fn, void *user) {
     c->ar = fn;
     c->ar_user = user;
+    c->ar_fast_all = -1;
+    return 0;
+}
+
+int lorads_hip_set_separable(lorads_hip_ctx *c, int32_t on) {
+    flush_pending(c);
+    c->sep = on != 0;
+    if (c->sep && !c->sepbuf && dalloc(&c->sepbuf, 32)) return 1;
     return 0;
 }
 
@@ -674,6 +692,16 @@ void *lorads_hip_stream(lorads_hip_ctx *c) { return (void *)c->stream; }
 /* all-reduce constrValSum through the registered hook (self-check of a hook / of the stream-ordered mode) */
 int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *c) {
     LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, 1.0, c->csum); // some work on the stream before the collective
+    if (c->ar && c->sep) {
+        // separable shards hold different numbers of constraints: the collective is one double (constrValSum[0]), spread over the
+        // vector afterwards -- the caller's check (every entry = the sum over the ranks) reads the same
+        if (c->m == 0) LAUNCH(k_zero, 1, (size_t)1, c->sepbuf + 16, NOGUARD);
+        else HC(hipMemcpyAsync(c->sepbuf + 16, c->csum, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (allreduce_dev(c, c->sepbuf + 16, 1)) return 1;
+        if (c->m) LAUNCH(k_fill_from, grid1d((size_t)c->m), (size_t)c->m, (const double *)(c->sepbuf + 16), c->csum);
+        HC(hipStreamSynchronize(c->stream));
+        return 0;
+    }
     if (allreduce_dev(c, c->csum, c->m)) return 1;
     LAUNCH(k_scale, grid1d((size_t)c->m), (size_t)c->m, 1.0, c->csum); // and after it
     HC(hipStreamSynchronize(c->stream));
@@ -688,10 +716,10 @@ int lorads_hip_init_constr(lorads_hip_ctx *c, int32_t pair) {
         constr_val(c, B, X + B.off, Y + B.off, 1.0, B.cv, CV_ADD, c->csum, NOGUARD);
         lp_col_values(c, B, X, Y, NOGUARD);
     }
-    return allreduce_dev(c, c->csum, c->m);
+    return shard_vec(c) ? allreduce_dev(c, c->csum, c->m) : 0; // (separable shards: these are the rank's own constraints)
 }
 
-static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
+static int enqueue_alm_grad(lorads_hip_ctx *c, double rho, bool reduce = true) {
     LAUNCH(k_zero, 1, (size_t)1, c->scal + 8, NOGUARD);
     std::vector<Block *> cones;
     Block *S1 = solo(c);
@@ -707,7 +735,7 @@ static int enqueue_alm_grad(lorads_hip_ctx *c, double rho) {
                      (B.dense_c || B.dense_a) ? B.Wd : nullptr);
         LAUNCH(k_finalize, 1, part_slot(c, 0), g, 1.0, 1, c->scal + 8, NOGUARD);
     }
-    return allreduce_dev(c, c->scal + 8, 1);
+    return reduce ? allreduce_dev(c, c->scal + 8, 1) : 0;
 }
 int lorads_hip_alm_cal_grad(lorads_hip_ctx *c, double rho, double *lag) {
     if (enqueue_alm_grad(c, rho)) return 1;
@@ -750,6 +778,34 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
             }
         }
         LAUNCH(k_use_grad_p, gv, n, pp[cur], gv, c->G, D);
+        return 0;
+    }
+    if (c->opt_gram && c->L <= 5) { // sharded cones: ONE collective for the whole direction (see k_gram)
+        if (inner == 0) { // D = -Grad; LBFGSDirUseGrad could only replace it by itself
+            LAUNCH(k_scale_copy, gv, n, -1.0, c->G, D);
+            return 0;
+        }
+        const int nn = inner <= c->L - 1 ? inner : c->L, nv = 2 * nn + 1, npair = nv * (nv + 1) / 2;
+        GramVecs V{};
+        GramPlan pl{};
+        pl.nn = nn;
+        V.v[0] = c->G;
+        for (int t = 0, node = (c->head - 1 + c->L) % c->L; t < nn; ++t, node = (node - 1 + c->L) % c->L) {
+            pl.node[t] = node;
+            V.v[1 + t] = c->ring[node].y;
+            V.v[1 + nn + t] = c->ring[node].s;
+        }
+        const int g = std::max(1, std::min(std::min(gv, 256), 5 * MAXPART / npair)); // (partials: slots 3..7, consumed at once)
+        double *part = part_slot(c, 3);
+#define GRAM_NV(NV_) case NV_: LAUNCH((k_gram<NV_>), g, n, V, part); break
+        switch (nv) { GRAM_NV(3); GRAM_NV(5); GRAM_NV(7); GRAM_NV(9); default: LAUNCH((k_gram<11>), g, n, V, part); break; }
+#undef GRAM_NV
+        LAUNCH(k_gram_final, 1, (const double *)part, npair, g, c->gram);
+        if (allreduce_dev(c, c->gram, npair)) return 1;
+        hipLaunchKernelGGL(k_lbfgs_coef, dim3(1), dim3(1), 0, c->stream, pl, (const double *)c->gram, c->ring_ab, c->gram + 80);
+#define LINC_NV(NV_) case NV_: LAUNCH((k_lincomb<NV_>), gv, n, V, (const double *)(c->gram + 80), D); break
+        switch (nv) { LINC_NV(3); LINC_NV(5); LINC_NV(7); LINC_NV(9); default: LAUNCH((k_lincomb<11>), gv, n, V, (const double *)(c->gram + 80), D); break; }
+#undef LINC_NV
         return 0;
     }
     if (inner == 0) {
@@ -814,10 +870,18 @@ static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
             if (g) LAUNCH(k_finalize, 1, part_slot(c, 4), g, scale, 1, c->q12 + 2 * m + pass, NOGUARD);
         }
     }
-    return allreduce_dev(c, c->q12, 2 * m + 2);
+    // (separable shards: q1, q2 are the rank's own; p1, p2 are summed where they are read)
+    return shard_vec(c) ? allreduce_dev(c, c->q12, 2 * m + 2) : 0;
 }
 int lorads_hip_alm_q12p12(lorads_hip_ctx *c, double p12[2]) {
     if (enqueue_q12p12(c)) return 1;
+    if (c->ar && c->sep) {
+        // the slot-by-slot line search that follows takes p1, p2 from the host: the summed pair goes to a buffer of its own
+        // and q12[2m..] keeps the local parts (launch_linesearch copies them next to the five local sums, unused there)
+        HC(hipMemcpyAsync(c->sepbuf + 8, c->q12 + 2 * c->m, sizeof(double) * 2, hipMemcpyDeviceToDevice, c->stream));
+        if (allreduce_dev(c, c->sepbuf + 8, 2)) return 1;
+        return read_scalars_at(c, c->sepbuf + 8, 2, p12);
+    }
     return read_scalars_at(c, c->q12 + 2 * c->m, 2, p12);
 }
 
@@ -839,6 +903,7 @@ static void launch_linesearch(lorads_hip_ctx *c, double rho, int np_obj) {
 }
 int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
     launch_linesearch(c, rho, 0);
+    if (c->ar && c->sep && allreduce_dev(c, c->scal + 16, 5)) return 1; // the five sums over every rank's constraints
     double s[5];
     if (read_scalars(c, 16, 5, s)) return 1;
     quartic_coeffs(rho, p1, p2, s, k);
@@ -885,7 +950,8 @@ static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner) {
     int np = 0;
     if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c, &np)) return 1;
     launch_linesearch(c, rho, np);
-    return 0;
+    // separable shards: the five m-vector sums and p1, p2 are this rank's parts -- one all-reduce of seven doubles
+    return (c->ar && c->sep) ? allreduce_dev(c, c->scal + 16, 7) : 0;
 }
 int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double out[6]) {
     if (enqueue_alm_front(c, rho, inner)) return 1;
@@ -897,8 +963,8 @@ int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double ou
 }
 int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
     Block *S1 = solo(c);
-    if (S1 && S1->nrow == c->m && c->m > 0 && !S1->dense_c && !S1->dense_a) {
-        // one cone that sees every constraint: 7 launches for the whole second half
+    if (S1 && !c->ar && S1->nrow == c->m && c->m > 0 && !S1->dense_c && !S1->dense_a) {
+        // one cone that sees every constraint (one rank: k_alm_tail forms 1/(y.s) from local sums): 7 launches for the whole second half
         Block &B = *S1;
         Ring &h = c->ring[c->head];
         const int gv = grid_lbfgs(c->all_elem);
@@ -916,6 +982,21 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), gv, c->ring_ab + 2 * c->head + 1, part_slot(c, 8),
                part_slot(c, 9), nres, c->scal);
         c->head = (c->head + 1) % c->L;
+    } else if (c->ar && c->sep && c->opt_gram) {
+        // separable shards: ||Grad||^2 and y.s of the step are local sums like the evaluation's -- they ride on ITS all-reduce
+        // (six doubles, one collective for the whole second half), and 1/(y.s) is formed from the summed value afterwards
+        Ring &h = c->ring[c->head];
+        const int hd = c->head;
+        if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho, false)) return 1;
+        LAUNCH(k_his_two, grid1d(c->all_elem), c->all_elem, tau, c->U, c->G, h.s, h.y);
+        if (dot_to_slot(c, h.y, h.s, 9, false)) return 1;
+        c->head = (c->head + 1) % c->L;
+        c->sep_extra.n = 2;
+        c->sep_extra.p[0] = c->scal + 8;
+        c->sep_extra.p[1] = c->scal + 9;
+        if (enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) return 1;
+        hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 9, c->ring_ab + 2 * hd, c->ring_ab + 2 * hd + 1,
+                           c->scal + 10);
     } else if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
                lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) {
         return 1;
@@ -978,7 +1059,7 @@ int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxi
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
     c->ls_np = 0;
     // (see pend_dual; with sharded cones only the one-kernel front can take it: it needs no owner pairs, k_wsum stores all of lambda)
-    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && (!c->ar || front_cw_ok(c, c->blk[0]))) {
+    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && (!shard_vec(c) || front_cw_ok(c, c->blk[0]))) {
         flush_pending(c);
         c->pend_dual = true;
         c->pend_dual_rho = rho;
@@ -992,6 +1073,7 @@ int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
     const int g = std::min(grid1d((size_t)c->m), 256);
     LAUNCH(k_dot, g, (size_t)c->m, c->b, c->lambda, part_slot(c, 7), NOGUARD);
     LAUNCH(k_finalize, 1, part_slot(c, 7), g, 1.0, 0, c->scal + 4, NOGUARD);
+    if (c->ar && c->sep && allreduce_dev(c, c->scal + 4, 1)) return 1; // (b and lambda are the rank's own pieces)
     return read_scalars(c, 4, 1, dobj);
 }
 

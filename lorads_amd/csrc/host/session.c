@@ -65,7 +65,7 @@ int lrd_session_prepare_sharded(lrd_session *s, int world, int rank_id, int allo
     double **R, **U, **V;
     lrd_init_point(s->prob, &R, &U, &V);
     int nb = s->prob->nblk;
-    if (world > 1 && allow_separable) lrd_problem_localize(s->prob, world, rank_id);
+    if (allow_separable) lrd_problem_localize(s->prob, world > 1 ? world : 1, world > 1 ? rank_id : 0); /* (world 1: the whole problem is "its own") */
     if (world > 1) {
         int *keep = (int *)calloc((size_t)nb, sizeof(int));
         int w = 0;

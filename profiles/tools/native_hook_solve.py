@@ -23,19 +23,22 @@ for name, params in [("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2)), ("rand120"
     with common.hip_session(common.instance_path(name), **params) as s:
         s.solve()
         ref = s.results()
-    s = common.hip_session(common.instance_path(name), world=1, rank=0, **params)
-    mode, _seen = bench.install_allreduce(s, dist, torch, device, 1, 0, "nccl")
-    s.solve()
-    got = s.results()
-    nat = getattr(s, "_rccl_native", None)
-    if nat:
-        s.hip_sync()
-        nat[0].lorads_rccl_comm_destroy(nat[1])
-    s.close()
-    # (the sharded phase 1 sums its dots over another partition of the vectors than the single-rank fused step: long runs
-    # separate by rounding, as in tests/test_multirank_hip.py -- converged objectives to 2e-6)
-    ok = all(abs(got[k] - ref[k]) <= 2e-6 * (1 + abs(ref[k])) for k in ("pObj", "dObj"))
-    bad += not ok
-    print(name, mode, "ok" if ok else "MISMATCH", got["pObj"], ref["pObj"], got["admm_iter"], ref["admm_iter"], got["alm_inner"], ref["alm_inner"])
+    for sep in (False, True):   # the m-vector form, then the scalars-only form of separable shards (one rank: trivially separable)
+        s = common.hip_session(common.instance_path(name), world=1, rank=0, separable=sep, **params)
+        assert s.separable == sep
+        mode, _seen = bench.install_allreduce(s, dist, torch, device, 1, 0, "nccl")
+        s.solve()
+        got = s.results()
+        nat = getattr(s, "_rccl_native", None)
+        if nat:
+            s.hip_sync()
+            nat[0].lorads_rccl_comm_destroy(nat[1])
+        s.close()
+        # (the sharded phase 1 sums its dots over another partition of the vectors than the single-rank fused step: long runs
+        # separate by rounding, as in tests/test_multirank_hip.py -- converged objectives to 2e-6)
+        ok = all(abs(got[k] - ref[k]) <= 2e-6 * (1 + abs(ref[k])) for k in ("pObj", "dObj"))
+        bad += not ok
+        print(name, mode, "separable" if sep else "m-vector", "ok" if ok else "MISMATCH", got["pObj"], ref["pObj"], got["admm_iter"], ref["admm_iter"],
+              got["alm_inner"], ref["alm_inner"])
 dist.destroy_process_group()
 sys.exit(1 if bad else 0)

@@ -39,11 +39,13 @@ def oracle_session(path, world=1, rank=0, **params):
     return s
 
 
-def hip_session(path, world=1, rank=0, **params):
+def hip_session(path, world=1, rank=0, separable=None, **params):
     s = host.Session.open(path)
     s.set_params(verbose=0, **params)
     # (sharded: a block-separable deal runs on per-rank sub-problems sharing scalars only; LORADS_SEPARABLE=0: the general form)
-    s.prepare(world, rank, separable=world > 1 and os.environ.get("LORADS_SEPARABLE", "1") != "0")
+    if separable is None:
+        separable = world > 1 and os.environ.get("LORADS_SEPARABLE", "1") != "0"
+    s.prepare(world, rank, separable=separable)
     s.attach_hip()
     return s
 

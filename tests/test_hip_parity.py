@@ -30,6 +30,34 @@ def test_trace_vs_reference_golden(built, name):
         s.close()
 
 
+@pytest.mark.parametrize("form", ["m-vector, one collective per dot", "m-vector, Gram-form direction", "separable, scalars only"])
+@pytest.mark.parametrize("name", ["rand120", "blk4x60", "mix4", "coupled3x70", "sdplp40", "densea40"])
+def test_sharded_forms_replay_the_reference_trace(built, monkeypatch, name, form):
+    """The code paths of sharded cones against the reference's own numbers: one rank with an all-reduce hook (the sum over one rank
+    is the identity), every lorads_func slot replayed from the golden trace -- in the m-vector form (constrValSum, q1, q2 through the
+    hook) with the L-BFGS direction by the sequential recursion (one collective per dot) and in Gram form (one collective for the
+    direction), and in the scalars-only form of separable shards (lorads_hip_set_separable)."""
+    monkeypatch.setenv("LORADS_LBFGS_GRAM", "0" if "per dot" in form else "1")
+    g = common.golden_trace(name)
+    s = common.hip_session(common.instance_path(name), separable=form.startswith("separable"))
+    calls = []
+    try:
+        assert s.separable == form.startswith("separable")
+        s.set_allreduce(lambda ptr, count, on_device: calls.append((count, on_device)))
+        log = common.replay_trace(s, g, rtol=1e-9, resync=True)
+        worst = max(e for _, e in log if not _[0:2] == "cg")
+        sizes = sorted({c for c, _ in calls})
+        print(name, form, "worst rel-to-scale error", worst, "collectives", len(calls), "sizes", sizes)
+        assert calls, "the hook was never called: not the sharded path"
+        if form.startswith("separable"):
+            # scalars only (at most the 15 products of the Gram-form direction): nothing of length m crosses the ranks
+            assert max(sizes) <= 66 and not any(c in (s.m, s.m + 2, 2 * s.m + 2) for c in sizes), sizes
+        else:
+            assert max(sizes) >= s.m
+    finally:
+        s.close()
+
+
 def _pair(path, **params):
     return common.hip_session(path, **params), common.oracle_session(path, **params)
 

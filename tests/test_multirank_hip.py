@@ -37,6 +37,8 @@ def _worker(rank, world, port, name, params, q):
         r = s.results()
         r["nblk_local"] = s.nblk
         r["mode"] = mode
+        r["separable"] = s.separable
+        r["m_local"] = s.m
         q.put((rank, r))
     finally:
         s.close()
@@ -48,14 +50,25 @@ def _worker(rank, world, port, name, params, q):
 # objective partials through the all-reduce and keeps the staged sums zeroed (no k_zero / k_stage_tail around the
 # collective); the parent's own session makes it five processes on the card (the box allows six)
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("name,params,world", [("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 2),
-                                               ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2),
-                                               ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 4)])
-def test_two_ranks_on_device_match_single_process(built, name, params, world):
+@pytest.mark.parametrize("name,params,world,separable", [
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 2, True),
+    ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, True),
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 4, True),
+    # the general sharded form (constrValSum, q1, q2 summed over the ranks as m-vectors): forced on a separable deal, and the only
+    # form there is when constraints touch cones of two ranks (coupled3x70)
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 2, False),
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 4, False),
+    ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False)])
+def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, params, world, separable):
+    """Sharded cones, one process per rank on the card.  separable=True: no constraint touches cones of two ranks, each rank works
+    on the sub-problem over its own constraints and the ranks share scalars only (lorads_hip_set_separable: four doubles per ADMM
+    iteration); False: the m-vector form."""
     from tests import common
     with common.hip_session(common.instance_path(name), **params) as s:
         s.solve()
         ref = s.results()
+        m_all, nb_all = s.m, s.nblk
+    monkeypatch.setenv("LORADS_SEPARABLE", "1" if separable else "0")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -71,13 +84,21 @@ def test_two_ranks_on_device_match_single_process(built, name, params, world):
         for p in procs:  # a rank stuck in a collective must not outlive the test
             if p.is_alive():
                 p.kill()
-    a, b = out[0], out[1]
-    assert all(out[r]["nblk_local"] == 4 // world for r in range(world))
+    a = out[0]
+    assert sum(out[r]["nblk_local"] for r in range(world)) == nb_all
+    assert all(out[r]["separable"] == separable for r in range(world))
+    if separable:
+        assert sum(out[r]["m_local"] for r in range(world)) == m_all       # the ranks' constraints partition the file's
+    else:
+        assert all(out[r]["m_local"] == m_all for r in range(world))
     assert a["admm_iter"] > 0, "phase 2 (the sharded evaluation) did not run"
     for r in range(1, world):
         for k in ("pObj", "dObj", "constrVio1", "pdGap", "admm_iter", "alm_inner"):
             assert a[k] == out[r][k], (r, k, a[k], out[r][k])
-    # block-separable constraints: Jacobi across ranks == Gauss-Seidel; only summation orders differ
+    print(name, world, "separable" if separable else "m-vector form", "pObj", a["pObj"], ref["pObj"], "dObj", a["dObj"], ref["dObj"],
+          "admm", a["admm_iter"], ref["admm_iter"], "alm inner", a["alm_inner"], ref["alm_inner"])
+    # block-separable constraints: Jacobi across ranks == Gauss-Seidel; only summation orders differ.  Coupled
+    # constraints: same fixed point, another trajectory.
     gold = [g for g in common.golden_solves() if g["instance"] == name and "1" in g["flags"][1:2]]
     assert a["pObj"] == pytest.approx(ref["pObj"], rel=2e-6)
     assert a["dObj"] == pytest.approx(ref["dObj"], rel=2e-6)
@@ -93,11 +114,12 @@ def test_native_rccl_hook_whole_solves_on_one_rank(built):
     """liblorads_rccl.so (ncclAllReduce in stream order on the library's stream, RCCL bound with dlopen) as the all-reduce
     hook of whole solves on an RCCL communicator of size 1 (the box has one GPU): every call site of the hook -- device
     buffers of the ADMM evaluation and of phase 1, host buffers of the rank agreement -- against the same solves
-    without a hook.  Runs as a child process (it initialises torch.distributed with the nccl backend)."""
+    without a hook; each in the m-vector form and in the scalars-only form of separable shards.  Runs as a child process (it initialises torch.distributed with the nccl backend)."""
     import subprocess
     tool = os.path.join(ROOT, "profiles", "tools", "native_hook_solve.py")
     env = dict(os.environ, MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=280, env=env)
     lines = [ln for ln in r.stdout.splitlines() if " rccl-native " in ln or " MISMATCH " in ln or " stream-ordered " in ln or " sync " in ln]
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert len(lines) == 4 and all(" rccl-native ok " in ln for ln in lines), lines
+    assert len(lines) == 8 and all(" rccl-native " in ln and " ok " in ln for ln in lines), lines
+    assert sum(" separable " in ln for ln in lines) == 4
