@@ -1301,6 +1301,20 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
     hipEvent_t e0, e1;
     HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
     const int grow = nblocks_for((size_t)B.n, TPB / 8), gcw = nblocks_for((size_t)B.nrow, TPB / 64);
+    // 40-44: the column-sliced experiment (see k_cw_sliced): sliced copies of x, V, an output and the slice parts of the weights
+    double *Xs = nullptr, *Vs = nullptr, *Os = nullptr, *wpart = nullptr, *wtot = nullptr;
+    if (which >= 40 && which <= 44) {
+        if (B.ca_ell <= 0 || B.ca_ell > 16 || (B.cell_w != 8 && B.cell_w != 16)) return fail_msg("ubench 40-44: needs fixed-width lists (<= 16 entries, 8 or 16 slots)");
+        if (dalloc(&Xs, len) || dalloc(&Vs, len) || dalloc(&Os, len) || dalloc(&wpart, (size_t)B.nrow * 8) || dalloc(&wtot, (size_t)B.nrow)) return 1;
+        LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, U, Xs);
+        LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, V, Vs);
+    }
+    const int gcs = 8 * nblocks_for((size_t)B.nrow, TPB / 16), gss = 8 * nblocks_for((size_t)B.n, TPB / 8);
+#define SPMM_SL(W_)                                                                                                                 \
+    do {                                                                                                                            \
+        if (B.cell_w == 8) LAUNCH((k_spmm_sliced<5, 8>), gss, B.n, B.cell_col, B.cell_con, B.cell_a, W_, Vs, Xs, Os);               \
+        else LAUNCH((k_spmm_sliced<5, 16>), gss, B.n, B.cell_col, B.cell_con, B.cell_a, W_, Vs, Xs, Os);                            \
+    } while (0)
     for (int it = -3; it < reps; ++it) { // three warm-up launches
         if (it == 0) HC(hipEventRecord(e0, c->stream));
         switch (which) {
@@ -1326,6 +1340,31 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             if (B.cell_w == 8) LAUNCH((k_front_cw<3, 8>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
             else LAUNCH((k_front_cw<3, 16>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
         } break;
+        case 40: LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart); break;
+        case 41: SPMM_SL((const double *)B.w_op); break;
+        case 42: LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, U, Xs); break;
+        case 43: // the whole sliced operator application
+            LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart);
+            LAUNCH(k_wsum8, nblocks_for((size_t)B.nrow, TPB), B.nrow, (const double *)wpart, wtot);
+            SPMM_SL((const double *)wtot);
+            break;
+        case 44: // ... with a streaming kernel over 19 MB in between (k_cg_update's traffic): the slices do not survive in L2
+            LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart);
+            LAUNCH(k_wsum8, nblocks_for((size_t)B.nrow, TPB), B.nrow, (const double *)wpart, wtot);
+            SPMM_SL((const double *)wtot);
+            LAUNCH(k_cg_update<true>, 512, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
+                   (const double *)nullptr, 0, c->st_shadow);
+            break;
+        case 45: // the row-major operator with the same streaming kernel in between (the pair to 44)
+            LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
+                   (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{});
+            if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
+                   B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
+            else LAUNCH((k_spmm_ell<8, true, 3, 16>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
+                   B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
+            LAUNCH(k_cg_update<true>, 512, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
+                   (const double *)nullptr, 0, c->st_shadow);
+            break;
         case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0.0,
                         c->m, (const double *)c->b, (const double *)c->csum, c->lambda); break;
         case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
@@ -1372,6 +1411,7 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
     HC(hipEventElapsedTime(&f, e0, e1));
     *ms = f;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(Xs); hipFree(Vs); hipFree(Os); hipFree(wpart); hipFree(wtot);
     invalidate_t(c);
     return 0;
 }
