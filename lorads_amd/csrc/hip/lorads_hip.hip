@@ -483,6 +483,8 @@ struct lorads_hip_ctx {
     double pend_dual_rho = 0.0;
     double *lambda_alt = nullptr;
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
+    bool opt_seg_lastblock = false; // lockstep sweep: the convergence test on k_cg_update_seg's last workgroup (LORADS_SEG_LASTBLOCK=1; measured slower than k_cg_check_seg: off)
+    int *seg_ticket = nullptr;     // its arrival counter (device, zero between launches)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
@@ -603,6 +605,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
     c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
+    c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
@@ -652,7 +655,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage); hipFree(c->sepbuf); hipFree(c->gram);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);

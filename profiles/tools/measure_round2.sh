@@ -14,8 +14,8 @@ bench)
   python profiles/tools/stamp.py r02 $O
   ;;
 prof)
-  for w in rand20000 maxcut20000 matcomp50000; do
-    TL=4.0; [ $w = matcomp50000 ] && TL=5.5
+  for w in rand20000 maxcut20000 matcomp50000 blk16x4000; do
+    TL=4.0; [ $w = matcomp50000 ] && TL=5.5; [ $w = blk16x4000 ] && TL=2.0
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o p -- python3 bench.py $B --workload $w --times-log-rank $TL --steps 50 --warmup 5 > $O/kt_$w.log 2>&1
     T=$(ls $O/kt_$w/*kernel_trace.csv | head -1)
     python profiles/trace_summary.py $T > $O/${w}_admm_part_summary.txt

@@ -856,6 +856,46 @@ def test_scalar_steps_on_carrier_kernels_are_bitwise_the_separate_launches(built
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name,tlr", [("blk4x60", None), ("mix4", None), ("blk16x4000", 2.0)])
+def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_launch(built, monkeypatch, name, tlr):
+    """Lockstep sweep: the per-cone convergence test between two CG iterations runs on the LAST workgroup of k_cg_update_seg to
+    finish (arrival counter, agent-scope loads of the other workgroups' partial sums) instead of the one-workgroup kernel
+    k_cg_check_seg (LORADS_SEG_LASTBLOCK=0).  Same sums in the same order: iterates, iteration counts and evaluations must be
+    bit-for-bit equal -- also on cfg4 at full size (16 cones of n = 4000: 544 workgroups per update, every XCD involved)."""
+    if name == "blk16x4000":
+        path = os.path.join("/tmp", "lorads_test_blk16x4000.dat-s")
+        if not os.path.exists(path):
+            from lorads_amd import instances
+            instances.write_sdpa(instances.NAMED["blk16x4000"](), path)
+    else:
+        path = common.instance_path(name)
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("LORADS_SEG_LASTBLOCK", on)
+        params = dict(phase1Tol=1e-1) if tlr is None else dict(phase1Tol=1e-1, timesLogRank=tlr)
+        s = common.hip_session(path, **params)
+        try:
+            s.alm()
+            s.alm_to_admm()
+            r0 = s.results()
+            rho = min(r0["admm_rho"] if r0["admm_rho"] > 0 else r0["alm_rho"], 5000.0)
+            s.be.init_constr(host.PAIR_UV)
+            log = []
+            for tol in (1e-6, 1e-9, 1e-4, 1e-12, 1e-8, 1e-8):
+                c, p_, d, e = s.be.admm_step(rho, tol, 300)
+                s.be.update_dual_var(rho)
+                log.append((c, p_, d, e))
+            res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)], [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)]))
+        finally:
+            s.close()
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    print(name, "CG iterations per step", [c for c, _, _, _ in la])
+    assert la == lb, (la, lb)
+    assert max(c for c, _, _, _ in la) > 2 * len(Ua)
+    for x, y in zip(Ua + Va, Ub + Vb):
+        assert np.array_equal(x, y)
+
+
 def test_carried_scalar_steps_on_a_grid_larger_than_the_device(built):
     """A carried scalar step sums partials at the top of its carrier; the carrier writes its own partials at its end.
     With more workgroups than the device holds at once (Max-Cut n = 20000, r = 40: 625 resident of 625; n = 48000: 1500
