@@ -27,12 +27,12 @@ def load_oracle():
     return _oracle
 
 
-def oracle_session(path, world=1, rank=0, **params):
+def oracle_session(path, world=1, rank=0, separable=False, **params):
     """Session driven by the CPU oracle table (tests / cpu_baseline only)."""
     lib = load_oracle()
     s = host.Session.open(path, lib=lib)
     s.set_params(verbose=0, **params)
-    s.prepare(world, rank)
+    s.prepare(world, rank, separable=separable)
     st = host.BackendStruct()
     assert lib.lorads_oracle_backend_create(s.problem_ptr(), 2, C.byref(st)) == 0
     s.attach(st)

@@ -23,11 +23,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, params, q):
+def _worker(rank, world, port, name, params, q, separable=False):
     sys.path.insert(0, ROOT)
     from tests import common
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     calls = [0]
+    longest = [0]
 
     def allreduce(ptr, count, on_device):
         assert not on_device
@@ -35,13 +36,17 @@ def _worker(rank, world, port, name, params, q):
         t = torch.from_numpy(a)  # shares memory: reduced in place
         dist.all_reduce(t)
         calls[0] += 1
+        longest[0] = max(longest[0], count)
 
-    s = common.oracle_session(common.instance_path(name), world=world, rank=rank, **params)
+    s = common.oracle_session(common.instance_path(name), world=world, rank=rank, separable=separable, **params)
     try:
         s.set_allreduce(allreduce)
         r = s.solve()
         r["nblk_local"] = s.nblk
         r["allreduce_calls"] = calls[0]
+        r["longest_collective"] = longest[0]
+        r["separable"] = s.separable
+        r["m_local"] = s.m
         q.put((rank, r))
     finally:
         s.close()
@@ -49,19 +54,25 @@ def _worker(rank, world, port, name, params, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,params", [("blk4x60", dict(reoptLevel=0)), ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2)),
-                                         ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7))])
-def test_two_ranks_match_single_process(name, params):
+@pytest.mark.parametrize("name,params,separable", [
+    ("blk4x60", dict(reoptLevel=0), False), ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), False),
+    ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), False),
+    # the separable form (what bench.py --gpus N runs): every rank on the sub-problem over its own constraints, scalars only
+    # through the hook -- the host's cut (lrd_problem_localize) and control flow with the checker's restatement of the mode
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), True), ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), True),
+    ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), True)])   # (asked for, not separable: stays m-vector)
+def test_two_ranks_match_single_process(name, params, separable):
     from tests import common
     s = common.oracle_session(common.instance_path(name), **params)
     try:
         ref = s.solve()
+        m_all = s.m
     finally:
         s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, params, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, params, q, separable)) for r in range(2)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=300) for _ in range(2))
@@ -70,11 +81,22 @@ def test_two_ranks_match_single_process(name, params):
         assert p.exitcode == 0
     a, b = out[0], out[1]
     assert a["nblk_local"] + b["nblk_local"] >= 3
+    if separable and name != "coupled3x70":
+        assert a["separable"] and b["separable"] and a["m_local"] + b["m_local"] == m_all
+        assert max(a["longest_collective"], b["longest_collective"]) <= 5      # scalars only
+    else:
+        assert not a["separable"] and not b["separable"] and a["m_local"] == b["m_local"] == m_all
+        assert a["longest_collective"] >= m_all
     assert a["allreduce_calls"] == b["allreduce_calls"] > 10
     # every rank holds the same global scalars
     for k in ("pObj", "dObj", "constrVio1", "pdGap", "admm_iter", "alm_inner"):
         assert a[k] == b[k], (k, a[k], b[k])
-    if name == "blk4x60":
+    if name == "mix4":
+        # separable, but a long phase 1 (11 000 inner iterations): the sums' orders differ -> converged objectives
+        assert abs(a["pObj"] - ref["pObj"]) <= 2e-6 * (1 + abs(ref["pObj"]))
+        assert abs(a["dObj"] - ref["dObj"]) <= 2e-6 * (1 + abs(ref["dObj"]))
+        assert a["constrVio1"] <= 1e-6
+    elif name == "blk4x60":
         # block-separable constraints: Gauss-Seidel over cones == Jacobi over ranks, so the
         # sharded run follows the single-process run; only the summation order of the all-reduce differs
         assert int(a["admm_iter"]) == int(ref["admm_iter"])
