@@ -1,0 +1,211 @@
+"""Randomized differential test: seeded random SDPs of random SHAPE -- number of cones, their sizes, which cones a constraint touches,
+diagonal / single-entry / dense / empty constraint matrices, cones without objective or without constraints, an optional LP block --
+through both operator tables (HIP C ABI vs the CPU oracle), function by function: two phase-1 inner iterations and two ADMM
+iterations from the same state.  The hand-made instances of tests/golden pick the reference's branches one at a time; this one
+mixes them the way files in the wild do (the unequal-length collective of the sharded path was found by such a mixture)."""
+import os
+
+import numpy as np
+import pytest
+
+from lorads_amd import host, instances
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(seed):
+    rng = np.random.default_rng(seed)
+    nb = int(rng.integers(1, 5))
+    dims = [int(rng.integers(2, 40)) for _ in range(nb)]
+    lp = rng.random() < 0.3
+    if lp:
+        dims.append(-int(rng.integers(1, 10)))
+    m = int(rng.integers(1, 50))
+    ent = {}
+
+    def put(mat, blk, i, j, v):
+        i, j = (i, j) if i <= j else (j, i)
+        ent[(mat, blk + 1, i + 1, j + 1)] = float(v)
+
+    # objective: sparse C per cone (some cones have none), positive LP costs
+    for k, d in enumerate(dims):
+        if d < 0:
+            for i in range(-d):
+                put(0, k, i, i, -(0.1 + rng.random()))           # F0 = -c => cost c > 0
+            continue
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            continue                                              # no objective on this cone
+        nnz = d if kind == 1 else int(rng.integers(1, 3 * d))
+        for _ in range(nnz):
+            i, j = (int(rng.integers(0, d)),) * 2 if kind == 1 else (int(rng.integers(0, d)), int(rng.integers(0, d)))
+            put(0, k, i, j, rng.normal())
+        for i in range(d):                                        # keep the problem bounded: a positive diagonal
+            put(0, k, i, i, -(0.5 + rng.random()))
+    sdp = [k for k, d in enumerate(dims) if d > 0]
+    touched = set()
+    for c in range(1, m + 1):
+        kind = rng.choice(["diag", "single", "sparse", "multi", "dense", "empty", "lp"], p=[0.2, 0.15, 0.3, 0.15, 0.08, 0.04, 0.08])
+        if kind == "empty":
+            continue
+        if kind == "lp":
+            if not lp:
+                kind = "sparse"
+            else:
+                for _ in range(int(rng.integers(1, 3))):
+                    i = int(rng.integers(0, -dims[-1]))
+                    put(c, len(dims) - 1, i, i, 0.2 + rng.random())
+                if rng.random() < 0.5:
+                    continue                                       # LP only
+                kind = "diag"
+        cones = list(rng.choice(sdp, size=min(len(sdp), int(rng.integers(2, 4))), replace=False)) if kind == "multi" else [int(rng.choice(sdp))]
+        for k in cones:
+            d = dims[k]
+            touched.add(k)
+            if kind == "diag":
+                for _ in range(int(rng.integers(1, 4))):
+                    i = int(rng.integers(0, d))
+                    put(c, k, i, i, 0.5 + rng.random())
+            elif kind == "single":
+                put(c, k, int(rng.integers(0, d)), int(rng.integers(0, d)), 1.0)
+            elif kind == "dense" and d <= 24:
+                for i in range(d):
+                    for j in range(i, d):
+                        put(c, k, i, j, rng.normal())
+            else:
+                for _ in range(int(rng.integers(1, 7))):
+                    put(c, k, int(rng.integers(0, d)), int(rng.integers(0, d)), rng.normal())
+    # b = A(X0) for a random PSD X0 of rank 2 (+ a positive LP point): feasible by construction
+    X0 = [None] * len(dims)
+    for k, d in enumerate(dims):
+        if d > 0:
+            R = rng.normal(size=(d, 2)) / np.sqrt(d)
+            X0[k] = R @ R.T
+        else:
+            X0[k] = np.diag(0.2 + rng.random(-d))
+    b = np.zeros(m)
+    for (mat, blk, i, j), v in ent.items():
+        if mat > 0:
+            b[mat - 1] += v * X0[blk - 1][i - 1, j - 1] * (1.0 if i == j else 2.0)
+    entries = sorted(((mat, blk, i, j, v) for (mat, blk, i, j), v in ent.items()), key=lambda e: (e[0], e[1], e[2], e[3]))
+    return dict(m=m, blocks=dims, b=b, entries=entries)
+
+
+CASES = [(seed, "one GPU") for seed in range(40)] + [(seed, form) for seed in range(40, 52) for form in ("sharded, m-vector form", "sharded, separable form")]
+
+
+@pytest.mark.parametrize("seed,form", CASES)
+def test_random_shapes_function_by_function_vs_oracle(built, seed, form):
+    """form: "one GPU", or the code paths of sharded cones with an all-reduce hook on one rank (the sum over one rank is the
+    identity): m-vectors through the hook, or the scalars-only form of separable shards."""
+    prob = random_problem(7000 + seed)
+    path = "/tmp/lorads_random_%d_%d.dat-s" % (os.getpid(), seed)
+    instances.write_sdpa(prob, path)
+    tlr = [1.0, 2.0, 3.5][seed % 3]
+    hs = common.hip_session(path, timesLogRank=tlr, separable=form.endswith("separable form"))
+    os_ = common.oracle_session(path, timesLogRank=tlr)
+    calls = []
+    if form != "one GPU":
+        hs.set_allreduce(lambda ptr, count, on_device: calls.append(count))
+    try:
+        nb = hs.nblk
+        assert nb == os_.nblk and hs.m == os_.m
+        rho = [0.3, 1.0, 4.0][seed % 3]
+
+        def mats(s, which):
+            return [s.be.get_mat(which, k) for k in range(nb)]
+
+        def close_all(A, B, tol, what):
+            for k, (x, y) in enumerate(zip(A, B)):
+                sc = max(np.abs(y).max(), 1e-300) if y.size else 1.0
+                assert np.allclose(x, y, rtol=0, atol=tol * sc), (what, k, float(np.abs(x - y).max()), sc)
+
+        def vec_close(x, y, tol, what):
+            sc = max(np.abs(y).max(), np.abs(np.asarray(prob["b"])).max(), 1e-12) if len(y) else 1.0
+            assert np.allclose(x, y, rtol=0, atol=tol * sc), (what, float(np.abs(x - y).max()), sc)
+
+        for it in range(2):
+            vals = []
+            for s in (hs, os_):
+                be = s.be
+                if it == 0:
+                    be.init_constr(host.PAIR_RR)
+                lag = be.alm_cal_grad(rho)
+                G = mats(s, host.MAT_GRAD)
+                be.lbfgs_direction(it)
+                p1, p2 = be.alm_q12p12()
+                kq = be.alm_linesearch_coeffs(rho, p1, p2)
+                vals.append((lag, p1, p2, kq, G, mats(s, host.MAT_U), be.get_vec(host.VEC_Q1), be.get_vec(host.VEC_Q2), be.get_vec(host.VEC_CONSTR_SUM)))
+            (la, p1a, p2a, ka, Ga, Da, q1a, q2a, ca), (lb, p1b, p2b, kb, Gb, Db, q1b, q2b, cb) = vals
+            assert np.isclose(la, lb, rtol=1e-9, atol=1e-300)
+            close_all(Ga, Gb, 1e-9, "Grad")
+            close_all(Da, Db, 1e-8, "D")
+            vec_close(ca, cb, 1e-10, "constrValSum")
+            vec_close(q1a, q1b, 1e-9, "q1")
+            vec_close(q2a, q2b, 1e-9, "q2")
+            sc = max(abs(p1b), abs(p2b), 1e-12)
+            assert abs(p1a - p1b) <= 1e-8 * sc and abs(p2a - p2b) <= 1e-8 * sc
+            assert np.allclose(ka, kb, rtol=1e-7, atol=1e-8 * max(max(abs(x) for x in kb), 1e-12))
+            tau, _ = common.linesearch_tau(kb)
+            for s in (hs, os_):
+                be = s.be
+                be.set_y_as_neg_grad()
+                be.alm_update_var(tau)
+                be.alm_cal_grad(rho)
+                be.set_lbfgs_his_two(tau)
+            ea, eb = hs.be.update_dimacs(host.PAIR_RR), os_.be.update_dimacs(host.PAIR_RR)
+            assert np.isclose(ea, eb, rtol=1e-8, atol=1e-14)
+            oa, ob = hs.be.cal_obj(host.PAIR_RR), os_.be.cal_obj(host.PAIR_RR)
+            assert np.isclose(oa, ob, rtol=1e-9, atol=1e-12)
+            close_all(mats(hs, host.MAT_R), mats(os_, host.MAT_R), 1e-9, "R")
+            for k in range(nb):   # identical states: errors must not compound
+                hs.be.set_mat(host.MAT_R, k, os_.be.get_mat(host.MAT_R, k))
+        for s in (hs, os_):
+            s.be.update_dual_var(rho)
+        vec_close(hs.be.get_vec(host.VEC_LAMBDA), os_.be.get_vec(host.VEC_LAMBDA), 1e-9, "lambda")
+        assert np.isclose(hs.be.cal_dual_obj(), os_.be.cal_dual_obj(), rtol=1e-9, atol=1e-12)
+        # The ADMM systems (I + rho A_V^* A_V) x = rhs are compared where CG CONVERGES (two runs of a CG that has lost its
+        # orthogonality on an ill-conditioned system agree in nothing but the residual): the condition number is 1 + ||A_V||^2
+        # whatever rho, so the factors are scaled to max |.| = 1 / (4 sqrt(1 + ||A||_F^2)) -- it is then below ten.
+        fro2 = sum(v * v * (1.0 if i == j else 2.0) for (mat, blk, i, j, v) in prob["entries"] if mat > 0)
+        rho2 = [0.3, 1.0, 4.0][(seed + 1) % 3]
+        for k in range(nb):
+            Rk = os_.be.get_mat(host.MAT_R, k)
+            Rk = Rk / max(np.abs(Rk).max(), 1e-300) / (4.0 * np.sqrt(1.0 + fro2))
+            for s in (hs, os_):
+                s.be.set_mat(host.MAT_R, k, Rk)
+        lam = os_.be.get_vec(host.VEC_LAMBDA)
+        lam = lam / max(np.abs(lam).max(), 1.0) if len(lam) else lam
+        for s in (hs, os_):
+            s.be.set_vec(host.VEC_LAMBDA, lam)
+            s.be.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+        for step in range(2):
+            # (no iteration limit in reach: a CG stopped before it has converged is compared with nothing but its own rounding)
+            ia = hs.be.admm_update_var(rho2, 1e-9, 20000)
+            ib = os_.be.admm_update_var(rho2, 1e-9, 20000)
+            close_all(mats(hs, host.MAT_U), mats(os_, host.MAT_U), 2e-6, "U")
+            close_all(mats(hs, host.MAT_V), mats(os_, host.MAT_V), 2e-6, "V")
+            # (counts: equal on the short solves; a solve of several hundred iterations -- the reference's restart every 20
+            # iterations halves the step, see the oracle's cg_solve -- ends a few restarts earlier or later with the rounding)
+            assert abs(ia - ib) <= max(3 * nb, 0.2 * ib), (step, ia, ib)
+            pa, pb = hs.be.cal_obj(host.PAIR_UV), os_.be.cal_obj(host.PAIR_UV)
+            assert np.isclose(pa, pb, rtol=1e-6, atol=1e-9)
+            ea, eb = hs.be.update_dimacs(host.PAIR_UV), os_.be.update_dimacs(host.PAIR_UV)
+            assert np.isclose(ea, eb, rtol=1e-4, atol=1e-9)
+            for s in (hs, os_):
+                s.be.update_dual_var(rho2)
+            for k in range(nb):
+                hs.be.set_mat(host.MAT_U, k, os_.be.get_mat(host.MAT_U, k))
+                hs.be.set_mat(host.MAT_V, k, os_.be.get_mat(host.MAT_V, k))
+            hs.be.set_vec(host.VEC_LAMBDA, os_.be.get_vec(host.VEC_LAMBDA))
+            hs.be.set_vec(host.VEC_CONSTR_SUM, os_.be.get_vec(host.VEC_CONSTR_SUM))
+        if form != "one GPU":
+            assert calls, "the hook was never called: not the sharded path"
+            if form.endswith("separable form"):
+                assert max(calls) <= 15, max(calls)       # scalars only
+    finally:
+        hs.close()
+        os_.close()
+        os.remove(path)
