@@ -423,7 +423,8 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         s.set_params(dyrankLevel=0)
     # cones dealt round-robin over the ranks; a block-separable deal (both workloads here) leaves each rank the sub-problem over
     # its own constraints, and the ranks share four scalars per ADMM iteration instead of the m-vector (LORADS_SEPARABLE=0: that)
-    s.prepare(world, rank, separable=world > 1 and os.environ.get("LORADS_SEPARABLE", "1") != "0")
+    # (LORADS_FORCE_DIST=1: the sharded code path on ONE rank -- the form's own cost, hook included -- takes the separable form too)
+    s.prepare(world, rank, separable=dist is not None and os.environ.get("LORADS_SEPARABLE", "1") != "0")
     t_setup1 = time.time()
     s.attach_hip()
     t_setup2 = time.time()
@@ -569,7 +570,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
                                        % ("cones dealt over the ranks" if strong else "block-per-GPU",
                                           "four scalars (separable shards: every rank holds its own constraints)" if s.separable
                                           else "the shared m-vector", ar_mode)) if world > 1 else "single GPU",
-                       "separable_shards": bool(s.separable) if world > 1 else None,
+                       "separable_shards": bool(s.separable) if dist is not None else None,
                        "flags": "--timesLogRank %g --phase1Tol 1e-2 (phase 1 untimed), fixed rho=%.6g" % (tlr, rho)},
             "state": {"pObj": pobj, "dObj": dobj, "err1_end": err1},
             # start-up cost, untimed: reader + host pre-solve (rank rule, start point), then the device image
