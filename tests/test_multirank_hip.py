@@ -33,8 +33,10 @@ def _worker(rank, world, port, name, params, q):
     s = common.hip_session(common.instance_path(name), world=world, rank=rank, **params)
     try:
         mode = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
+        s.hip_profile(1, 1 << 30)   # (counts the solves resumed after a missed speculation)
         s.solve()
         r = s.results()
+        r["speculation_misses"] = int(s.hip_profile_read()["matvec_ms_est"])
         r["nblk_local"] = s.nblk
         r["mode"] = mode
         r["separable"] = s.separable
@@ -58,17 +60,25 @@ def _worker(rank, world, port, name, params, q):
     # form there is when constraints touch cones of two ranks (coupled3x70)
     ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 2, False),
     ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 4, False),
-    ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False)])
+    ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False),
+    # speculation window 1 (enqueue what the previous sweep needed): a miss every other iteration -- the "somebody missed, everybody
+    # evaluates again" protocol of both forms at work (the default window's runs above already miss at different iterations per rank)
+    ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, True),
+    ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False)])
 def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, params, world, separable):
     """Sharded cones, one process per rank on the card.  separable=True: no constraint touches cones of two ranks, each rank works
     on the sub-problem over its own constraints and the ranks share scalars only (lorads_hip_set_separable: four doubles per ADMM
     iteration); False: the m-vector form."""
     from tests import common
+    provoke = name.endswith("+misses")
+    name = name.split("+")[0]
     with common.hip_session(common.instance_path(name), **params) as s:
         s.solve()
         ref = s.results()
         m_all, nb_all = s.m, s.nblk
     monkeypatch.setenv("LORADS_SEPARABLE", "1" if separable else "0")
+    if provoke:
+        monkeypatch.setenv("LORADS_SPEC_WINDOW", "1")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -92,6 +102,10 @@ def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, para
     else:
         assert all(out[r]["m_local"] == m_all for r in range(world))
     assert a["admm_iter"] > 0, "phase 2 (the sharded evaluation) did not run"
+    misses = [out[r]["speculation_misses"] for r in range(world)]
+    print(name, "speculation misses per rank", misses)
+    if provoke:
+        assert sum(misses) > 50, misses   # (the ranks really missed, far more often than with the default window)
     for r in range(1, world):
         for k in ("pObj", "dObj", "constrVio1", "pdGap", "admm_iter", "alm_inner"):
             assert a[k] == out[r][k], (r, k, a[k], out[r][k])
