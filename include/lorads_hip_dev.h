@@ -30,7 +30,8 @@ int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes
 /* which kernels apply the CG operator of block blk: 0 = k_pairdots + k_sgram + k_spmm (Gram of the A_i),
  * 1 = k_pairdots + k_cv + k_sval + k_spmm, 2 = k_op_diag (every A_i one diagonal entry), 3 = k_op_entry (every A_i
  * one entry), 4 = k_cw + k_spmm_ell (constraint values straight from the factors, slot coefficients a w_i);
- * + 16: the cone also holds DENSE constraint matrices, whose part of A / A^* runs through the dense GEMM (k_dense_cx_b) */
+ * + 16: the cone also holds DENSE constraint matrices, whose part of A / A^* runs through the dense GEMM (k_dense_cx_b)
+ * + 32: kind 3 in its two-colour form (bipartite entry graph: k_op_entry_bip, one launch per colour) */
 int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
 
 #ifdef __cplusplus

@@ -424,6 +424,9 @@ struct Block {
     double *lp_a = nullptr, *lp_nrm2sq = nullptr, *lp_cobj = nullptr, *lp_cv = nullptr;
     bool entry_only = false;  // every A_i is a single (off-)diagonal entry (matrix completion): k_op_entry
     double *gentry = nullptr; // sum of a_i^2 per A-pattern entry
+    int *bip_rows[2] = {nullptr, nullptr}; // single-entry cone whose entry graph is bipartite: the rows of either colour (k_op_entry_bip)
+    int bip_n[2] = {0, 0};
+    double *bip_we = nullptr;  // per entry: ge (x_p.V_q + x_q.V_p) of the running operator application, colour 0 -> colour 1
     int cg_iter_last = 0;     // lorads_cg_linsys.iter survives an immediate exit (lorads_cgs.c:157-160,173)
     int spec[2] = {1, 1};     // speculated CG iterations of the U- and V-solve: the largest count of the last few sweeps
     int spec_hist[2][8] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
@@ -483,6 +486,7 @@ struct lorads_hip_ctx {
     double pend_dual_rho = 0.0;
     double *lambda_alt = nullptr;
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
+    bool opt_entry_bip = true; // single-entry cones with a bipartite entry graph: k_op_entry_bip x 2 (LORADS_ENTRY_BIP=0: k_op_entry)
     bool opt_seg_lastblock = false; // lockstep sweep: the convergence test on k_cg_update_seg's last workgroup (LORADS_SEG_LASTBLOCK=1; measured slower than k_cg_check_seg: off)
     int *seg_ticket = nullptr;     // its arrival counter (device, zero between launches)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
@@ -606,6 +610,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
+    c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
@@ -647,7 +652,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
-        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.rc_con); hipFree(B.gentry); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
+        hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.rc_con); hipFree(B.gentry); hipFree(B.bip_rows[0]); hipFree(B.bip_rows[1]); hipFree(B.bip_we); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
         hipFree(B.d_con); hipFree(B.Adense); hipFree(B.Sfull); hipFree(B.d_mu); hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
         hipFree(B.w_uv); hipFree(B.w_op); hipFree(B.lp_lvl_ptr); hipFree(B.lp_lvl_cols); hipFree(B.lp_ptr); hipFree(B.lp_grow);
         hipFree(B.lp_a); hipFree(B.lp_nrm2sq); hipFree(B.lp_cobj); hipFree(B.lp_cv); hipFree(B.g_ptr); hipFree(B.g_col);
@@ -1424,6 +1429,7 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     const Block &B = c->blk[k];
     *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.use_cw ? 4 : B.has_gram ? 0 : 1;
     if (B.dense_a) *kind += 16; // + dense constraint matrices through the dense GEMM
+    if (B.entry_only && B.bip_rows[0] && c->opt_entry_bip) *kind += 32; // single-entry operator in its two-colour form (k_op_entry_bip x 2)
     return 0;
 }
 

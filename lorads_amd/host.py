@@ -415,6 +415,8 @@ class Session:
         k = C.c_int()
         _check(lib.lorads_hip_operator_kind(ctx, blk, C.byref(k)), "operator_kind")
         base = ["k_pairdots+k_sgram+k_spmm2", "k_pairdots+k_cv+k_sval+k_spmm2", "k_op_diag", "k_op_entry", "k_cw+k_spmm_ell"][k.value & 15]
+        if k.value & 32:   # bipartite entry graph: one launch per colour
+            base = "k_op_entry_bip+k_op_entry_bip"
         return base + ("+k_dense_cx_b(dense A_i)" if k.value & 16 else "")
 
     def hip_stream(self):

@@ -44,6 +44,10 @@ ks = out["kernels"]
 if "k_op_diag" in ks:
     op = ks["k_op_diag"]["read_bytes_median"] + ks["k_op_diag"]["write_bytes_mean"]
     out["cg_operator_application"] = {"kernels": ["k_op_diag"], "traffic_bytes": op}
+elif "k_op_entry_bip" in ks:
+    # two launches per application (the two colours of the entry graph): per-launch means over both sides, times two
+    op = 2 * (ks["k_op_entry_bip"]["read_bytes_mean"] + ks["k_op_entry_bip"]["write_bytes_mean"])
+    out["cg_operator_application"] = {"kernels": ["k_op_entry_bip", "k_op_entry_bip"], "traffic_bytes": op}
 elif "k_op_entry" in ks:
     op = ks["k_op_entry"]["read_bytes_median"] + ks["k_op_entry"]["write_bytes_mean"]
     out["cg_operator_application"] = {"kernels": ["k_op_entry"], "traffic_bytes": op}

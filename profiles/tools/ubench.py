@@ -28,7 +28,7 @@ NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>",
 PROBE_BYTES = {20: 40000 * 64 * 320, 21: 40000 * 64 * 320, 22: 40000 * 64 * 320, 23: 20000 * 16 * 320, 24: 20000 * 16 * 320}
 
 
-ENTRY = {100: "k_op_entry (whole operator, single-entry constraints)",
+ENTRY = {100: "k_op_entry / k_op_entry_bip x 2 (whole operator, single-entry constraints; LORADS_ENTRY_BIP=0: the former)",
          120: "gather probe on this cone: 16 random rows of V per row", 121: "gather probe on this cone: rows of x and V in turn"}
 
 
@@ -41,6 +41,8 @@ def main():
     path = bench.build_instance(workload, "/tmp/lorads_bench_%s.dat-s" % workload)
     s = host.Session.open(path)
     s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+    if workload == "matcomp50000":
+        s.set_params(dyrankLevel=0)   # (r = 60 as BASELINE cfg5 names it; with rank growth phase 1 ends at r = 90)
     s.prepare(1, 0)
     s.attach_hip()
     s.alm()

@@ -896,6 +896,41 @@ def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_laun
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name,tlr", [("matcomp60", None), ("matcomp4000", 3.0)])
+def test_bipartite_entry_operator_equals_the_one_kernel_form(built, monkeypatch, name, tlr):
+    """Single-entry cones whose entry graph is bipartite (matrix completion): k_op_entry_bip forms every entry's pair dot once, on
+    the rows of one colour, and hands it to the rows of the other colour (3 gathered rows per entry instead of 4).  Same sums up
+    to the order of two additions: iterates to 1e-10 of scale, equal CG iteration counts, against k_op_entry (LORADS_ENTRY_BIP=0)."""
+    path = common.instance_path(name) if name == "matcomp60" else _gen(name)
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("LORADS_ENTRY_BIP", on)
+        params = dict(phase1Tol=1e-1) if tlr is None else dict(phase1Tol=1e-1, timesLogRank=tlr)
+        s = common.hip_session(path, **params)
+        try:
+            assert s.hip_operator_kind(0) == ("k_op_entry_bip+k_op_entry_bip" if on == "1" else "k_op_entry")
+            s.alm()
+            s.alm_to_admm()
+            r0 = s.results()
+            rho = min(r0["admm_rho"] if r0["admm_rho"] > 0 else r0["alm_rho"], 5000.0)
+            s.be.init_constr(host.PAIR_UV)
+            log = []
+            for tol in (1e-6, 1e-9, 1e-4, 1e-10):
+                c, p_, d, e = s.be.admm_step(rho, tol, 300)
+                s.be.update_dual_var(rho)
+                log.append((c, p_, d, e))
+            res.append((log, s.be.get_mat(host.MAT_U, 0), s.be.get_mat(host.MAT_V, 0)))
+        finally:
+            s.close()
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    print(name, "CG iterations per step", [c for c, _, _, _ in la], [c for c, _, _, _ in lb])
+    assert [c for c, _, _, _ in la] == [c for c, _, _, _ in lb]
+    assert max(c for c, _, _, _ in la) > 4
+    for (_, pa, da, ea), (_, pb, db, eb) in zip(la, lb):
+        assert np.isclose(pa, pb, rtol=1e-10) and np.isclose(da, db, rtol=1e-10) and np.isclose(ea, eb, rtol=1e-7, atol=1e-14)
+    assert np.allclose(Ua, Ub, rtol=0, atol=1e-10 * np.abs(Ub).max()) and np.allclose(Va, Vb, rtol=0, atol=1e-10 * np.abs(Vb).max())
+
+
 def test_carried_scalar_steps_on_a_grid_larger_than_the_device(built):
     """A carried scalar step sums partials at the top of its carrier; the carrier writes its own partials at its end.
     With more workgroups than the device holds at once (Max-Cut n = 20000, r = 40: 625 resident of 625; n = 48000: 1500
@@ -1115,7 +1150,7 @@ def test_cfg5_slots_vs_oracle_fullsize(built):
     hs, os_ = _pair(path, timesLogRank=5.5)
     try:
         assert hs.block_shape(0) == (50000, 60) and hs.m == 200000
-        assert hs.hip_operator_kind(0) == "k_op_entry"
+        assert hs.hip_operator_kind(0) == "k_op_entry_bip+k_op_entry_bip"   # (the entry graph of a matrix completion is bipartite)
         rho = 0.5
         for it in range(3):
             vals = []
