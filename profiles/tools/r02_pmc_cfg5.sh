@@ -10,7 +10,7 @@ rm -f $O/p5_*/*counter_collection.csv
 python - "$O/pmc_matcomp50000.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-for k in ("k_op_entry", "k_cg_update", "k_cg_dir", "k_spmm2"):
+for k in ("k_op_entry_bip", "k_op_entry", "k_cg_update", "k_cg_dir", "k_spmm2"):
     v = d["kernels"].get(k)
     if v: print(k, v["launches"], round(v["read_bytes_median"] / 1e6, 1), round(v["write_bytes_mean"] / 1e6, 1))
 PY
