@@ -514,7 +514,12 @@ struct lorads_hip_ctx {
     // a direction update (k_cg_dir) waiting for the row-local operator that follows it (k_op_diag forms the rows of p
     // itself); sent off as its own launch if anything else comes first
     struct PendDir { int kind = 0; CGState *st = nullptr; double *r = nullptr, *p = nullptr; size_t len = 0; int gv = 0;
-                     const double *rs_part = nullptr; int rs_np = 0; Guard g{}; bool seg = false; int half = 0; } pend_dir;
+                     const double *rs_part = nullptr; int rs_np = 0; Guard g{}; bool seg = false; int half = 0;
+                     const double *chk_part = nullptr; double chk_tol = 0; int chk_maxit = 0, chk_k = 0; } pend_dir; // chk_*: lockstep test riding with the direction
+    struct PendSegChk { bool on = false; int half = 0, k = 0; const double *part = nullptr; double tol = 0; int maxit = 0; } pend_segchk;
+    double *seg_rr_alt = nullptr; // second slot of every stage's r.r (see SegArgs)
+    int *seg_tile_info = nullptr; // int4 per row tile of the merged cone (see DirArgs.seg_info)
+    bool opt_seg_carry = true;    // LORADS_SEG_CARRY=0: k_cg_check_seg after every update of the lockstep sweep
     int *seg_tile_cone = nullptr;             // row tile (workgroup of a row kernel) -> cone, merged cone
     CGState *h_st = nullptr;  // pinned mirror
     double *h_scal = nullptr; // pinned mirror of scalars
@@ -611,6 +616,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
+    c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
@@ -660,7 +666,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage); hipFree(c->sepbuf); hipFree(c->gram);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket); hipFree(c->seg_rr_alt); hipFree(c->seg_tile_info);
     hipFree(c->ring_ab);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
