@@ -561,7 +561,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             "dtype": "f64", "data": "synthetic",
             "ranks_seen": ranks_seen,
             "admm_iters_per_s_of_the_sharded_problem": a.steps / elapsed,
-            "speculation_misses_in_timed_region": int(prof["matvec_ms_est"]),   # (solves resumed after a host round trip)
+            "speculation_misses_in_timed_region": int(prof["speculation_misses"]),   # (solves resumed after a host round trip)
             "cg_iters_per_s": cg_iters / elapsed,
             "cg_iters_per_admm_iter": cg_iters / units,
             "config": {"workload": cfg_txt,

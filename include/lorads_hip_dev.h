@@ -33,6 +33,9 @@ int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes
  * + 16: the cone also holds DENSE constraint matrices, whose part of A / A^* runs through the dense GEMM (k_dense_cx_b)
  * + 32: kind 3 in its two-colour form (bipartite entry graph: k_op_entry_bip, one launch per colour) */
 int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
+/* replay of captured launch chains (hipGraph; LORADS_GRAPH=0 switches it off): stats = {chains captured, chains replayed,
+ * chains held now, 1 if the replay is enabled for this context} */
+int lorads_hip_graph_stats(lorads_hip_ctx *ctx, int64_t stats[4]);
 
 #ifdef __cplusplus
 }

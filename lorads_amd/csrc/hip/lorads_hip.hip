@@ -60,6 +60,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -217,29 +218,43 @@ __device__ __forceinline__ bool blocked(const Guard &g) { return gate_blocked(g,
 //    a copy k_cg_update (and the solve's init) leave behind, so that workgroup 0 can write the new state into `st`
 //    while the other workgroups are still reading.  Re-running a test whose update was skipped (solve already finished)
 //    reproduces the same state from the same shadow and partials.
+// A scalar of the step that is either passed by value or read from the device-resident step parameters (lorads_hip_ctx::par).
+// The launch chain of an ADMM iteration that is replayed as a captured hipGraph must not carry rho, the CG tolerance or the
+// iteration limit in its kernel ARGUMENTS (they are frozen at capture): such a chain is enqueued with p != null, and the host
+// changes the values with one tiny launch (k_set_par) only when they change (rho every rhoFreq iterations, lorads_admm.c:121-138;
+// the tolerance follows the primal infeasibility, :76).  Same bits either way.
+struct DS {
+    const double *p;
+    double v;
+    __host__ __device__ DS(double x = 0.0) : p(nullptr), v(x) {}
+    __host__ __device__ DS(const double *q, double x) : p(q), v(x) {}
+};
+__device__ __forceinline__ double dsv(const DS &s) { return s.p ? *s.p : s.v; }
 struct InitArgs {
     CGState *st;              // nullptr: nothing to do
     CGState *shadow;
     const double *part_rr, *part_b;
     int nrr, nb;
-    double tol;
+    DS tol;
 };
 struct Deferred {
     CGState *st;              // nullptr: nothing pending
     const CGState *shadow;
     const double *part;       // partials of ||r||^2 left by the update
-    int np, maxit;
-    double tol;
+    int np;
+    DS maxit;                 // (an integer kept as a double)
+    DS tol;
     const int *need;          // the solve's own gate (previous stage finished)
 };
 struct DefOut { int done; double beta; };
 // in two halves, like the carried start: the loads first (before the carrier's own), the decision where it is needed
-struct DefPriv { double rr_old, bnorm, beta0, a; int it0, done0, needw; };
+struct DefPriv { double rr_old, bnorm, beta0, a, tol; int it0, done0, needw, maxit; };
 __device__ __forceinline__ DefPriv deferred_private(const Deferred &d) {
     DefPriv v;
     v.rr_old = d.shadow->rr; v.bnorm = d.shadow->bnorm; v.beta0 = d.shadow->beta;
     v.it0 = d.shadow->iter; v.done0 = d.shadow->done;
     v.needw = *(d.need ? d.need : &d.shadow->done); // (no branch around the load)
+    v.tol = dsv(d.tol); v.maxit = (int)dsv(d.maxit);
     v.a = private_partials(d.part, d.np);
     return v;
 }
@@ -251,7 +266,7 @@ __device__ __forceinline__ DefOut finish_deferred(const Deferred &d, const DefPr
     if (v.done0 != 0) { o.done = v.done0; o.beta = v.beta0; return o; } // finished before this test (e.g. at the initial residual)
     const int it = v.it0 + 1;                                           // lorads_cgs.c:189-194, :217-224 (as k_cg_check)
     o.beta = a / v.rr_old;
-    o.done = sqrt(a) / v.bnorm < d.tol ? 1 : (it >= d.maxit ? 3 : 0);
+    o.done = sqrt(a) / v.bnorm < v.tol ? 1 : (it >= v.maxit ? 3 : 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.st->iter = it;
         if (a != a) d.st->nan = 1;
@@ -284,7 +299,7 @@ __device__ __forceinline__ void init_private(const InitArgs &ia, double (&iv)[2]
 // ... and the workgroup reduction + decision (same sums as sum_partials); returns the solve's `done` word or -1 (gated)
 __device__ __forceinline__ int finish_init(const InitArgs &ia, bool open, double (&iv)[2], double *sh8) {
     block_sum_n<2>(iv, sh8);
-    const bool conv = sqrt(iv[0]) / iv[1] < ia.tol;
+    const bool conv = sqrt(iv[0]) / iv[1] < dsv(ia.tol);
     if (!open) return -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CGState s;
@@ -301,7 +316,7 @@ __device__ __forceinline__ int run_init(const InitArgs &ia, const Guard &g, doub
     const bool open = !(g.need && *g.need == 0);
     const double a = sum_partials(ia.part_rr, ia.nrr, sh);
     const double b = sum_partials(ia.part_b, ia.nb, sh);
-    const bool conv = sqrt(a) / b < ia.tol;
+    const bool conv = sqrt(a) / b < dsv(ia.tol);
     if (!open) return -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CGState s;
@@ -437,6 +452,7 @@ struct Block {
 struct Ring {
     double *s = nullptr, *y = nullptr;
 };
+struct GraphCache; // captured launch chains (graph.inc)
 
 } // namespace
 
@@ -477,7 +493,16 @@ struct lorads_hip_ctx {
     int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
     char *ctrl = nullptr, *h_ctrl = nullptr; // [64 scalars | CG states] device + pinned mirror: ONE readback copy
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
-    unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number
+    unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr, pub_seq = 0; // published sequence number (the host's count)
+    unsigned long long *seq_dev = nullptr;   // ... and the device's: every hand-over kernel bumps it (see k_publish)
+    // Step parameters in device memory {rho, CG tolerance, rho of the pending dual update, CG iteration limit} (see DS): the launch
+    // chain of an ADMM iteration refers to them by address while par_mode is on, so that a captured chain can be replayed
+    double *par = nullptr;
+    double par_h[4] = {0, 0, 0, 0};          // what the device holds
+    int par_valid = 0;                       // bit k: par_h[k] is on the device
+    bool par_mode = false;
+    bool opt_graph = true;                   // LORADS_GRAPH=0: every iteration enqueued launch by launch
+    GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
     // from the updated multipliers and stores them to lambda_alt, then the two vectors swap); sent off as k_dual_update
@@ -547,6 +572,10 @@ struct lorads_hip_ctx {
 
 namespace {
 
+inline DS ds_rho(const lorads_hip_ctx *c, double v) { return c->par_mode ? DS(c->par + 0, v) : DS(v); }
+inline DS ds_tol(const lorads_hip_ctx *c, double v) { return c->par_mode ? DS(c->par + 1, v) : DS(v); }
+inline DS ds_rho_dual(const lorads_hip_ctx *c, double v) { return c->par_mode ? DS(c->par + 2, v) : DS(v); }
+inline DS ds_maxit(const lorads_hip_ctx *c, int v) { return c->par_mode ? DS(c->par + 3, (double)v) : DS((double)v); }
 inline int nblocks_for(size_t items, int per_block) { return (int)((items + per_block - 1) / per_block); }
 // grid of the L-BFGS stage kernels: every workgroup re-sums the previous stage's partials, so keep them few
 inline int grid_lbfgs(size_t len);
@@ -600,10 +629,13 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
         dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) || dalloc(&c->gram, 128) ||
         dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
-        dalloc(&c->ring_ab, (size_t)2 * c->L)) {
+        dalloc(&c->ring_ab, (size_t)2 * c->L) || dalloc(&c->par, 8) || dalloc(&c->seq_dev, 2)) {
         lorads_hip_destroy(c);
         return 1;
     }
+    HC(hipMemset(c->par, 0, sizeof(double) * 8));
+    HC(hipMemset(c->seq_dev, 0, sizeof(unsigned long long) * 2));
+    c->opt_graph = !(getenv("LORADS_GRAPH") && getenv("LORADS_GRAPH")[0] == '0');
     HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1), hipHostMallocMapped));
     HC(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocMapped));
     *c->h_flag = 0;
@@ -667,7 +699,8 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     free_factors(c);
     hipFree(c->cstage); hipFree(c->sepbuf); hipFree(c->gram);
     hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket); hipFree(c->seg_rr_alt); hipFree(c->seg_tile_info);
-    hipFree(c->ring_ab);
+    hipFree(c->ring_ab); hipFree(c->par); hipFree(c->seq_dev);
+    graph_cache_free(c);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->h_flag) hipHostFree(c->h_flag);
@@ -1379,7 +1412,7 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
             LAUNCH(k_cg_update<true>, 512, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
                    (const double *)nullptr, 0, c->st_shadow);
             break;
-        case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0.0,
+        case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0, DS(0.0),
                         c->m, (const double *)c->b, (const double *)c->csum, c->lambda); break;
         case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
                        (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
@@ -1436,6 +1469,14 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     *kind = B.diag_only ? 2 : B.entry_only ? 3 : B.use_cw ? 4 : B.has_gram ? 0 : 1;
     if (B.dense_a) *kind += 16; // + dense constraint matrices through the dense GEMM
     if (B.entry_only && B.bip_rows[0] && c->opt_entry_bip) *kind += 32; // single-entry operator in its two-colour form (k_op_entry_bip x 2)
+    return 0;
+}
+
+int lorads_hip_graph_stats(lorads_hip_ctx *c, int64_t stats[4]) {
+    stats[0] = c->graphs ? c->graphs->n_capture : 0;
+    stats[1] = c->graphs ? c->graphs->n_replay : 0;
+    stats[2] = c->graphs ? (int64_t)c->graphs->map.size() : 0;
+    stats[3] = graph_ok(c) ? 1 : 0;
     return 0;
 }
 

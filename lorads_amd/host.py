@@ -373,7 +373,7 @@ class Session:
         lib, ctx = self._hip()
         out = (C.c_double * 8)()
         _check(lib.lorads_hip_profile_read(ctx, out), "profile_read")
-        keys = ["matvec_launches", "matvec_ms_est", "cg_iters", "cg_solves", "sampled", "sampled_ms", "spmm_sampled",
+        keys = ["matvec_launches", "speculation_misses", "cg_iters", "cg_solves", "sampled", "sampled_ms", "spmm_sampled",
                 "spmm_sampled_ms"]
         return dict(zip(keys, [out[i] for i in range(8)]))
 
@@ -409,6 +409,14 @@ class Session:
         v, lm, mv = C.c_double(), (C.c_double * max(nb, 1))(), C.c_int()
         _check(lib.lorads_hip_dual_infeasibility(ctx, tol, ncv, max_restarts, C.byref(v), lm, C.byref(mv)), "dual_infeasibility")
         return v.value, [lm[i] for i in range(nb)], mv.value
+
+    def hip_graph_stats(self):
+        """{captured, replayed, held, enabled} of the launch-chain replay (hipGraph) of this context"""
+        lib, ctx = self._hip()
+        out = (C.c_int64 * 4)()
+        lib.lorads_hip_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_graph_stats(ctx, out), "graph_stats")
+        return dict(zip(["captured", "replayed", "held", "enabled"], [int(out[i]) for i in range(4)]))
 
     def hip_operator_kind(self, blk=0):
         lib, ctx = self._hip()

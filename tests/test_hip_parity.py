@@ -1224,3 +1224,62 @@ def test_cfg5_slots_vs_oracle_fullsize(built):
     finally:
         hs.close()
         os_.close()
+
+
+@pytest.mark.parametrize("name,tlr,nobatch", [("maxcut100", None, False), ("blk4x60", None, False), ("blk4x60", None, True),
+                                              ("mix4", None, False), ("rand120", None, False), ("rand4000", 4.0, False),
+                                              ("maxcut800", None, False), ("sdplp40", None, False)])
+def test_graph_replay_is_bitwise_the_launch_by_launch_iteration(built, name, tlr, nobatch):
+    """An ADMM iteration whose launch chain has been seen before is replayed as a captured hipGraph (graph.inc): rho, the CG
+    tolerance, the iteration limit and the hand-over's sequence number live in device memory, so a replay runs exactly the
+    kernels the enqueue would have launched, with the same arguments.  LORADS_GRAPH=0 enqueues every iteration launch by
+    launch.  The two must agree BIT FOR BIT -- CG iteration counts, objectives, factors, multipliers -- over iterations that
+    change rho and the tolerance, miss their speculation (resumed launch by launch), mix the fused step with the
+    slot-by-slot calls, and cross the periodic exact constraint refresh (every 32nd sweep: a chain of its own)."""
+    path = _gen(name) if name in ("rand4000",) else common.instance_path(name)
+    if nobatch:
+        os.environ["LORADS_NO_BATCH"] = "1"
+    res = []
+    try:
+        for graph in ("1", "0"):
+            os.environ["LORADS_GRAPH"] = graph
+            try:
+                kw = dict(phase1Tol=1e-2)
+                if tlr:
+                    kw["timesLogRank"] = tlr
+                s = common.hip_session(path, **kw)
+            finally:
+                os.environ.pop("LORADS_GRAPH", None)
+            try:
+                s.alm()           # the solver's own phase 1 (the same launches either way: phase 1 is not replayed)
+                s.alm_to_admm()
+                s.be.init_constr(host.PAIR_UV)
+                res0 = s.results()
+                rho = min(res0["admm_rho"] if res0["admm_rho"] > 0 else res0["alm_rho"], 5000.0)   # (the hand-off's penalty, as bench.py)
+                log = []
+                tols = [1e-8, 1e-8, 1e-8, 1e-8, 1e-3, 1e-8, 1e-8, 1e-12, 1e-8, 1e-8]
+                for it in range(70):
+                    if it % 7 == 6:
+                        c = s.be.admm_update_var(rho, tols[it % len(tols)], 800)
+                        p, d, e = s.be.cal_obj(host.PAIR_UV), s.be.cal_dual_obj(), s.be.update_dimacs(host.PAIR_UV)
+                    else:
+                        c, p, d, e = s.be.admm_step(rho, tols[it % len(tols)], 800 if it != 33 else 3)
+                    s.be.update_dual_var(rho)
+                    if it % 10 == 9:
+                        rho *= 1.2
+                    log.append((c, p, d, e))
+                assert all(np.isfinite(x[1]) and np.isfinite(x[3]) for x in log), log[-3:]
+                st = s.hip_graph_stats()
+                res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)],
+                            [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)], s.be.get_vec(host.VEC_LAMBDA), st))
+            finally:
+                s.close()
+    finally:
+        os.environ.pop("LORADS_NO_BATCH", None)
+    (la, Ua, Va, lama, sta), (lb, Ub, Vb, lamb, stb) = res
+    assert sta["enabled"] == 1 and sta["replayed"] >= 20, sta   # (most iterations are replays ...)
+    assert stb["enabled"] == 0 and stb["captured"] == 0 and stb["replayed"] == 0, stb   # (... and none with the switch off)
+    assert la == lb, [(i, x, y) for i, (x, y) in enumerate(zip(la, lb)) if x != y][:3]
+    assert np.array_equal(lama, lamb)
+    for x, y in zip(Ua + Va, Ub + Vb):
+        assert np.array_equal(x, y)

@@ -32,13 +32,15 @@ def _worker(rank, world, port, name, params, q):
     torch.cuda.set_device(device)
     s = common.hip_session(common.instance_path(name), world=world, rank=rank, **params)
     try:
-        mode = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
+        mode, seen = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
+        assert seen == world, ("ranks seen by the library's own hook", seen, world)
         s.hip_profile(1, 1 << 30)   # (counts the solves resumed after a missed speculation)
         s.solve()
         r = s.results()
-        r["speculation_misses"] = int(s.hip_profile_read()["matvec_ms_est"])
+        r["speculation_misses"] = int(s.hip_profile_read()["speculation_misses"])
         r["nblk_local"] = s.nblk
         r["mode"] = mode
+        r["ranks_seen"] = seen
         r["separable"] = s.separable
         r["m_local"] = s.m
         q.put((rank, r))
