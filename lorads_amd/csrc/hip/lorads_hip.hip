@@ -502,6 +502,7 @@ struct lorads_hip_ctx {
     int par_valid = 0;                       // bit k: par_h[k] is on the device
     bool par_mode = false;
     bool opt_graph = true;                   // LORADS_GRAPH=0: every iteration enqueued launch by launch
+    bool opt_graph_batched = false;          // LORADS_GRAPH=2: the lockstep sweep of a merged cone is replayed too
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
@@ -636,6 +637,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipMemset(c->par, 0, sizeof(double) * 8));
     HC(hipMemset(c->seq_dev, 0, sizeof(unsigned long long) * 2));
     c->opt_graph = !(getenv("LORADS_GRAPH") && getenv("LORADS_GRAPH")[0] == '0');
+    c->opt_graph_batched = getenv("LORADS_GRAPH") && getenv("LORADS_GRAPH")[0] == '2';
     HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1), hipHostMallocMapped));
     HC(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocMapped));
     *c->h_flag = 0;

@@ -43,7 +43,8 @@ for fam in ("rand", "maxcut"):
         op_ms = s.hip_ubench(200, 200) / 200
         mv, _ = s.hip_algorithmic_bytes(0)
         info = s.block_info(0)
-        print("%-10s %7d %4d %9d | %9.1f %10.1f %7.4f | %8.2f %9.2f %6.1f | %s" %
+        gs = s.hip_graph_stats()
+        print("%-10s %7d %4d %9d | %9.1f %10.1f %7.4f | %8.2f %9.2f %6.1f | %s | graph replays %d captures %d" %
               (fam, n, info["rank"], info["nrow"], steps / el, cg / el, 1e3 * el / steps, 1e3 * op_ms, mv / 1e6, 100 * mv / (op_ms * 1e-3) / 8e12,
-               s.hip_operator_kind(0)), flush=True)
+               s.hip_operator_kind(0), gs["replayed"], gs["captured"]), flush=True)
         s.close()

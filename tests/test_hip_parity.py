@@ -1241,7 +1241,7 @@ def test_graph_replay_is_bitwise_the_launch_by_launch_iteration(built, name, tlr
         os.environ["LORADS_NO_BATCH"] = "1"
     res = []
     try:
-        for graph in ("1", "0"):
+        for graph in ("2", "0"):   # (2: the lockstep sweep of merged cones is replayed too)
             os.environ["LORADS_GRAPH"] = graph
             try:
                 kw = dict(phase1Tol=1e-2)
