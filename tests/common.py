@@ -164,8 +164,13 @@ def replay_trace(sess, g, rtol=1e-9, atol=1e-13, resync=True):
     if resync:
         l1 = float(g["admm_init_scalars"][2])
     cg_total = 0
-    # the CG solves amplify rounding by the conditioning of (I + A_V^* A_V): looser tolerance
-    cg_rtol = max(rtol * 1e4, 1e-7)
+    # The CG solves amplify rounding by the conditioning of (I + A_V^* A_V).  With the state re-synchronised after every step the
+    # device's iterates sit 1e-15 ... 3e-14 of scale from the reference's on all twelve golden instances (sparse and dense mode
+    # alike; measured round 3, profiles/r03_trace_errors.txt): the bounds are 1e-9 for factors and m-vectors, 1e-11 for the
+    # objectives -- four to five orders above what is achieved, four below what they were (1e-5).  Without re-synchronisation
+    # (errors compound over the steps) the older bound stays.
+    cg_rtol = 1e-9 if resync else max(rtol * 1e4, 1e-7)
+    obj_rtol = 1e-11 if resync else cg_rtol
     for it in range(n_admm):
         tol = min(l1 * 1e-2, 1e-8)
         cg_total += be.admm_update_var(rho, tol, 800)
@@ -177,8 +182,8 @@ def replay_trace(sess, g, rtol=1e-9, atol=1e-13, resync=True):
         dobj = be.cal_dual_obj()
         l1 = be.update_dimacs(host.PAIR_UV)
         sc = g["admm_scalars_%d_0" % it]
-        _cmp("admm_pobj_%d" % it, pobj, sc[0], cg_rtol, atol, log)
-        _cmp("admm_dobj_%d" % it, dobj, sc[1], cg_rtol, atol, log)
+        _cmp("admm_pobj_%d" % it, pobj, sc[0], obj_rtol, atol, log)
+        _cmp("admm_dobj_%d" % it, dobj, sc[1], obj_rtol, atol, log)
         _cmp("admm_err1_%d" % it, l1, sc[2], cg_rtol * 10, 1e-12, log)
         # sparse-mode runs (no dense scratch matrix anywhere: the reference sums in the same sparse order): the CG must stop at
         # the same iteration as the reference's; the reference's dense branch rounds differently, so a test that sits on the
@@ -200,6 +205,19 @@ def replay_trace(sess, g, rtol=1e-9, atol=1e-13, resync=True):
             l1 = float(sc[2])
             cg_total = int(sc[4])
     return log
+
+
+def trace_worst(log):
+    """worst rel-to-scale error of a replay, by group: phase 1, ADMM factors, ADMM m-vectors, ADMM objectives, err1"""
+    def worst(pred):
+        v = [e for n_, e in log if pred(n_)]
+        return max(v) if v else 0.0
+    adm = ("U_", "V_", "csum_uv", "admm_", "csum_rr", "lambda_", "cg_")
+    return dict(phase1=worst(lambda n_: not n_.startswith(adm) or n_ == "lambda_alm"),
+                factors=worst(lambda n_: n_.startswith(("U_", "V_"))),
+                vectors=worst(lambda n_: n_.startswith(("csum_uv", "csum_rr", "lambda_")) and n_ != "lambda_alm"),
+                objectives=worst(lambda n_: n_.startswith(("admm_pobj", "admm_dobj"))),
+                err1=worst(lambda n_: n_.startswith("admm_err1")))
 
 
 def slack_matrices(prob, lam):

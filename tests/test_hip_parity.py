@@ -24,8 +24,11 @@ def test_trace_vs_reference_golden(built, name):
     try:
         assert s.be.name == "hip-gfx950"
         log = common.replay_trace(s, g, rtol=1e-9, resync=True)
-        worst = max(e for _, e in log if not _[0:2] == "cg")
-        print(name, "worst rel-to-scale error", worst)
+        w = common.trace_worst(log)
+        print(name, "worst rel-to-scale errors", w)
+        # what is achieved, not just what the slot-by-slot bounds allow (a 1e4x regression must not pass): phase 1 has 9e-13 at worst
+        # (theta30, the dense branch), the ADMM part 3e-14
+        assert w["phase1"] <= 1e-10 and w["factors"] <= 1e-11 and w["vectors"] <= 1e-11 and w["objectives"] <= 1e-12, w
     finally:
         s.close()
 
@@ -45,9 +48,10 @@ def test_sharded_forms_replay_the_reference_trace(built, monkeypatch, name, form
         assert s.separable == form.startswith("separable")
         s.set_allreduce(lambda ptr, count, on_device: calls.append((count, on_device)))
         log = common.replay_trace(s, g, rtol=1e-9, resync=True)
-        worst = max(e for _, e in log if not _[0:2] == "cg")
+        w = common.trace_worst(log)
         sizes = sorted({c for c, _ in calls})
-        print(name, form, "worst rel-to-scale error", worst, "collectives", len(calls), "sizes", sizes)
+        print(name, form, "worst rel-to-scale errors", w, "collectives", len(calls), "sizes", sizes)
+        assert w["phase1"] <= 1e-9 and w["factors"] <= 1e-10 and w["vectors"] <= 1e-10 and w["objectives"] <= 1e-11, w
         assert calls, "the hook was never called: not the sharded path"
         if form.startswith("separable"):
             # scalars only (at most the 15 products of the Gram-form direction): nothing of length m crosses the ranks
@@ -1332,3 +1336,78 @@ def test_rank_growth_on_the_device_fullsize(built):
             assert np.isfinite(p_) and np.isfinite(e_)
         finally:
             s.close()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name,tlr,its", [("rand20000", 4.0, 6), ("maxcut20000", 4.0, 6), ("blk16x4000", 2.0, 5), ("matcomp50000", 5.5, 4),
+                                          # the reference's DENSE branch (dsyr2k / dsymm round differently from any sparse order): cfg1's
+                                          # look-alike and matcomp60 over 25 iterations from the same start -- north_star's 1e-6 pinned
+                                          # on iterates that cannot wander to another stationary point, as whole solves of these two can
+                                          ("theta50", None, 25), ("matcomp60", None, 25), ("densec40", None, 25)])
+def test_fullsize_admm_iterations_from_the_devices_own_state_vs_compiled_reference(built, name, tlr, its):
+    """BASELINE cfg3b / cfg3a / cfg4 / cfg5 at full size: the device runs its own phase 1, its (U, V, lambda) go to the COMPILED
+    REFERENCE (oracle/_ref/ref_driver admmbench -- ref_driver64, the 64-bit index build, where n^2 > 2^31), which runs `its` ADMM
+    iterations of LORADSUpdateSDPVar + objective + DIMACS + dual update from that state on the host; the device then replays the same
+    iterations from the same state.  Same penalty, same tolerance rule.  Demanded: the same number of CG iterations, objectives equal
+    to 1e-10 relative, err1 to the seven digits the driver prints (what bench.py reports as parity_full_size in its line, here as an
+    assertion)."""
+    import subprocess
+    import bench
+    n_by = {"rand20000": 20000, "maxcut20000": 20000, "blk16x4000": 4000, "matcomp50000": 50000}.get(name, 100)
+    dense_branch = name in ("theta50", "matcomp60", "densec40")
+    wide = n_by * n_by > 2**31 - 1
+    drv = os.path.join(common.ROOT, "oracle", "_ref", "ref_driver64" if wide else "ref_driver")
+    if not os.path.exists(drv):
+        pytest.skip("compiled reference not present (oracle/_ref travels with the snapshot from the build container)")
+    path = common.instance_path(name) if dense_branch else _gen(name)
+    s = host.Session.open(path)
+    s.set_params(verbose=0, phase1Tol=1e-2, reoptLevel=0)
+    if tlr:
+        s.set_params(timesLogRank=tlr)
+    tlr = tlr or 2.0    # (the reference's default, main.c:29)
+    if name == "matcomp50000":
+        s.set_params(dyrankLevel=0)      # (r = 60 as BASELINE names it)
+    s.prepare(1, 0)
+    s.attach_hip()
+    state = "/tmp/lorads_test_state_%d_%s.bin" % (os.getpid(), name)
+    try:
+        s.alm()
+        s.alm_to_admm()
+        res = s.results()
+        rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
+        be = s.be
+        UV0 = [(be.get_mat(host.MAT_U, k), be.get_mat(host.MAT_V, k)) for k in range(s.nblk)]
+        lam0 = be.get_vec(host.VEC_LAMBDA)
+        with open(state, "wb") as f:
+            for U, V in UV0:
+                f.write(np.asfortranarray(U).tobytes(order="F"))
+                f.write(np.asfortranarray(V).tobytes(order="F"))
+            f.write(lam0.tobytes())
+        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1",
+                   LORADS_REF_UV_RANKS=",".join(str(s.block_shape(k)[1]) for k in range(s.nblk)))
+        if wide:
+            env["MKL_INTERFACE_LAYER"] = "ILP64"
+        r = subprocess.run([drv, path, "admmbench", "-", "--timesLogRank", repr(tlr), "--rho", repr(rho), "--uv", state, "--nADMM", str(its)],
+                           env=env, capture_output=True, text=True, timeout=1400)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("@@REF_ADMM_BENCH")]
+        assert r.returncode == 0 and line, r.stderr[-800:]
+        ref = dict(x.split("=") for x in line[0].split()[1:])
+        be.init_constr(host.PAIR_UV)
+        be.cal_obj(host.PAIR_UV)
+        e0 = be.update_dimacs(host.PAIR_UV)
+        e1, cg1, p1, d1 = bench.admm_steps(be, host, rho, e0, its, s)
+        print(name, "reference", ref, "device", dict(pObj=p1, dObj=d1, err1=e1, cg_iters=cg1))
+        if dense_branch:   # (a CG that stops on the threshold may fall the other way under the dense branch's rounding)
+            assert abs(int(cg1) - int(ref["cg_iters"])) <= max(3, 0.02 * int(ref["cg_iters"])), (cg1, ref["cg_iters"])
+            assert p1 == pytest.approx(float(ref["pObj"]), rel=1e-8, abs=1e-9)      # (north_star asks 1e-6)
+            assert d1 == pytest.approx(float(ref["dObj"]), rel=1e-8, abs=1e-9)
+            assert e1 == pytest.approx(float(ref["err1"]), rel=1e-5, abs=1e-12)
+            return
+        assert int(cg1) == int(ref["cg_iters"]), (cg1, ref["cg_iters"])
+        assert p1 == pytest.approx(float(ref["pObj"]), rel=1e-10, abs=1e-10)
+        assert d1 == pytest.approx(float(ref["dObj"]), rel=1e-10, abs=1e-10)
+        assert e1 == pytest.approx(float(ref["err1"]), rel=5e-7, abs=1e-14)   # (the driver prints seven digits of it)
+    finally:
+        s.close()
+        if os.path.exists(state):
+            os.remove(state)
