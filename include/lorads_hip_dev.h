@@ -33,6 +33,13 @@ int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes
  * + 16: the cone also holds DENSE constraint matrices, whose part of A / A^* runs through the dense GEMM (k_dense_cx_b)
  * + 32: kind 3 in its two-colour form (bipartite entry graph: k_op_entry_bip, one launch per colour) */
 int lorads_hip_operator_kind(lorads_hip_ctx *ctx, int32_t blk, int32_t *kind);
+/* the device image lorads_hip_create built for block blk (the device-side half of the pre-solve: AConePresolveData,
+ * data/lorads_sdp_conic.c:868-1076; sdpDataMatSetData, data/lorads_sdp_data.c:811-828): image[0..15] = {n, rank, constraints held,
+ * nnz of the held A_i (sparse ones), nnz of C, unique positions of the A_i, unique positions of C u A_i (A_i alone when C is stored
+ * dense), C stored dense (the reference's rule), dense constraint matrices kept full, Max-Cut-type cone, single-entry cone,
+ * constraint-wise operator, Gram form available, one-kernel front available, fixed width of the slot list, rows of either colour
+ * of a bipartite entry graph (0: not bipartite) packed as colour-0 count} */
+int lorads_hip_block_image(lorads_hip_ctx *ctx, int32_t blk, int64_t image[16]);
 /* replay of captured launch chains (hipGraph; LORADS_GRAPH=0 switches it off): stats = {chains captured, chains replayed,
  * chains held now, 1 if the replay is enabled for this context} */
 int lorads_hip_graph_stats(lorads_hip_ctx *ctx, int64_t stats[4]);

@@ -1484,6 +1484,15 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     return 0;
 }
 
+int lorads_hip_block_image(lorads_hip_ctx *c, int32_t k, int64_t im[16]) {
+    if (k < 0 || k >= c->nb) return fail_msg("bad block");
+    const Block &B = c->blk[k];
+    const int64_t v[16] = {B.n, B.r, B.nrow, B.na, B.nc, B.pa.ne, B.pu.ne, B.dense_c, B.dense_a ? B.nd : 0, B.diag_only, B.entry_only,
+                           B.use_cw, B.has_gram, B.front_cw, B.cell_w, B.bip_n[0]};
+    for (int i = 0; i < 16; ++i) im[i] = v[i];
+    return 0;
+}
+
 int lorads_hip_graph_stats(lorads_hip_ctx *c, int64_t stats[4]) {
     stats[0] = c->graphs ? c->graphs->n_capture : 0;
     stats[1] = c->graphs ? c->graphs->n_replay : 0;

@@ -410,6 +410,16 @@ class Session:
         _check(lib.lorads_hip_dual_infeasibility(ctx, tol, ncv, max_restarts, C.byref(v), lm, C.byref(mv)), "dual_infeasibility")
         return v.value, [lm[i] for i in range(nb)], mv.value
 
+    def hip_block_image(self, blk=0):
+        """what lorads_hip_create built for cone blk (see lorads_hip_dev.h)"""
+        lib, ctx = self._hip()
+        out = (C.c_int64 * 16)()
+        lib.lorads_hip_block_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_block_image(ctx, blk, out), "block_image")
+        keys = ["n", "rank", "nrow", "na", "nc", "pattern_a", "pattern_union", "dense_c", "dense_a", "diag_only", "entry_only", "use_cw",
+                "has_gram", "front_cw", "slot_width", "bip_rows0"]
+        return dict(zip(keys, [int(out[i]) for i in range(16)]))
+
     def hip_graph_stats(self):
         """{captured, replayed, held, enabled} of the launch-chain replay (hipGraph) of this context"""
         lib, ctx = self._hip()

@@ -9,6 +9,10 @@ oracle/_ref, see oracle/Makefile `make ref`).  What is committed is DATA only:
                                      sequence (oracle/ref_driver.c, mode `trace`)
   tests/golden/solve.json            final objectives / DIMACS errors / iteration counts / log lines of
                                      whole solves (mode `solve`) for several flag sets
+  tests/golden/presolve.json         what the reference's pre-solve decided for every cone of every instance (mode
+                                     `presolve`: cone type, constraints held, scratch-matrix type and pattern size,
+                                     coefficient matrices by type, rank); `python oracle/make_golden.py presolve`
+                                     writes this file alone
 
 usage: python oracle/make_golden.py            (from the repo root)
 """
@@ -97,13 +101,34 @@ def run_ref(args):
     return r.stdout
 
 
+def presolve_goldens(names):
+    out = {}
+    for n in names:
+        for tlr in ("2.0", "4.0"):
+            txt = run_ref([os.path.join(GOLD, n + ".dat-s"), "presolve", "-", "--timesLogRank", tlr])
+            cones = []
+            for ln in txt.splitlines():
+                if ln.startswith("@@REF_PRESOLVE "):
+                    cones.append({k: int(v) for k, v in (x.split("=") for x in ln.split()[1:])})
+                elif ln.startswith("@@REF_PRESOLVE_END"):
+                    tail = {k: int(v) for k, v in (x.split("=") for x in ln.split()[1:])}
+            out["%s@%s" % (n, tlr)] = dict(tail, cones=cones)
+        print("presolve", n, len(cones), "cone(s)")
+    with open(os.path.join(GOLD, "presolve.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
     names = sorted(set(TRACE) | {n for n, _ in SOLVE})
+    if sys.argv[1:] == ["presolve"]:   # (the instances are there already: this file alone)
+        presolve_goldens(names)
+        return
     for n in names:
         path = os.path.join(GOLD, n + ".dat-s")
         gen_instances.write_sdpa(gen_instances.NAMED[n](), path)
+    presolve_goldens(names)
     for n, (nalm, nadmm, extra) in TRACE.items():
         dump = "/tmp/_golden_%s.bin" % n
         run_ref([os.path.join(GOLD, n + ".dat-s"), "trace", dump, "--nALM", str(nalm), "--nADMM", str(nadmm)] + extra)

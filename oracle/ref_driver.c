@@ -198,6 +198,37 @@ static void dump_final(ctx_t *c, int dump_state) {
     }
 }
 
+/* presolve = what AConeProcData / AConePresolveData / LORADSDetermineRank decided for every cone (data/lorads_sdp_conic.c:868-1076,
+ * data/lorads_sdp_data.c:811-828, io/lorads_user_data.c:58): one line per cone, read by oracle/make_golden.py into
+ * tests/golden/presolve.json.  counts[] = coefficient matrices by type INCLUDING the objective (sdpConeStats). */
+static int mode_presolve(ctx_t *c) {
+    lorads_solver *S = c->S;
+    for (int k = 0; k < c->nBlks; ++k) {
+        lorads_sdp_cone *cone = S->SDPCones[k];
+        const int sparse_cone = cone->type == LORADS_CONETYPE_SPARSE_SDP;
+        long held, nz, nsp, nds;
+        int obj_type;
+        if (sparse_cone) {
+            lorads_cone_sdp_sparse *d = (lorads_cone_sdp_sparse *)cone->coneData;
+            held = (long)d->nRowElem; nz = (long)d->sdpConeStats[SDP_COEFF_ZERO]; nsp = (long)d->sdpConeStats[SDP_COEFF_SPARSE];
+            nds = (long)d->sdpConeStats[SDP_COEFF_DENSE]; obj_type = (int)d->sdpObj->dataType;
+        } else {
+            lorads_cone_sdp_dense *d = (lorads_cone_sdp_dense *)cone->coneData;
+            held = (long)d->nRow; nz = (long)d->sdpConeStats[SDP_COEFF_ZERO]; nsp = (long)d->sdpConeStats[SDP_COEFF_SPARSE];
+            nds = (long)d->sdpConeStats[SDP_COEFF_DENSE]; obj_type = (int)d->sdpObj->dataType;
+        }
+        const int wdense = cone->sdp_coeff_w_sum->dataType == SDP_COEFF_DENSE;
+        const long n = (long)c->BlkDims[k];
+        long wnnz = wdense ? n * (n + 1) / 2 : (long)((sdp_coeff_sparse *)cone->sdp_coeff_w_sum->dataMat)->nTriMatElem;
+        long onnz = cone->sdp_obj_sum->dataType == SDP_COEFF_DENSE ? n * (n + 1) / 2
+                                                                    : (long)((sdp_coeff_sparse *)cone->sdp_obj_sum->dataMat)->nTriMatElem;
+        printf("@@REF_PRESOLVE cone=%d n=%ld rank=%ld cone_sparse=%d rows_held=%ld wsum_dense=%d wsum_nnz=%ld objsum_nnz=%ld n_zero=%ld n_sparse=%ld n_dense=%ld obj_type=%d\n",
+               k, n, (long)S->var->rankElem[k], sparse_cone, held, wdense, wnnz, onnz, nz, nsp, nds, obj_type);
+    }
+    printf("@@REF_PRESOLVE_END m=%ld nblk=%ld nlp=%ld\n", (long)c->nConstrs, (long)c->nBlks, (long)c->nLpCols);
+    return 0;
+}
+
 /* solve = main.c:321-398 without the ARPACK step and without the level-2 reopt loop (which is
  * conditioned on the ARPACK result, main.c:414-476) */
 static int mode_solve(ctx_t *c, lorads_params *p, int dump_state) {
@@ -455,6 +486,7 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[2], "solve")) rc = mode_solve(&c, &p, dump_state);
     else if (!strcmp(argv[2], "trace")) rc = mode_trace(&c, &p, n_alm, n_admm, fixrho);
     else if (!strcmp(argv[2], "admmbench")) rc = mode_admm_bench(&c, &p, n_admm, uvfile, fixrho);
+    else if (!strcmp(argv[2], "presolve")) rc = mode_presolve(&c);
     else { fprintf(stderr, "unknown mode\n"); rc = 2; }
     if (g_dump) fclose(g_dump);
     fflush(stdout);
