@@ -35,8 +35,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def traffic_from_profiles(workload):
-    """HBM-side bytes per CG operator application from the committed PMC passes (profiles/, collected with
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; see profiles/pmc_summary.py)"""
+    """The committed PMC summary of this workload (profiles/*_pmc_<workload>.json: fabric-side bytes per launch of the operator's
+    and the front's kernels, collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; see
+    profiles/pmc_summary.py) and its path"""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -46,7 +47,7 @@ def traffic_from_profiles(workload):
         return None, None
     with open(best) as fh:
         d = json.load(fh)
-    return d.get("cg_operator_application", {}).get("traffic_bytes"), os.path.relpath(best, ROOT)
+    return d, os.path.relpath(best, ROOT)
 
 
 def rocprof_from_profiles(workload, op_kernels):
@@ -499,9 +500,12 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
         win_ms.append(1e3 * w / a.steps)
-    # ---- untimed roofline pass: EVERY operator application between two HIP events until enough samples exist, then the
-    # live operator back to back with nothing riding along (ubench variant 200: boundaries included, no event latency)
-    roof_samples, alone_ms, kern_ms = [], None, {}
+    # ---- untimed roofline pass: the launches the timed iterations make anyway, between two HIP events each, until enough samples
+    # exist -- first every CG operator application, then every solve front (right-hand side + initial residual) -- and the live
+    # operator back to back with nothing riding along (boundaries included, no event latency).  Nothing runs differently
+    # because it is timed.
+    roof_samples, front_samples, alone_ms = [], [], None
+    fronts_per_step = 2.0 * nloc
     if a.roofline_samples > 0:
         per_step = prof["matvec_launches"] / max(a.steps, 1)
         if dist:   # every rank must run the same number of (collective-carrying) iterations
@@ -509,28 +513,22 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             per_step = float(t.item())
         per_step = max(per_step, 0.25)
-        todo = int(min(4000, np.ceil(a.roofline_samples / per_step))) + 2
-        chunk = int(max(1, min(todo, 600 // max(1.0, 1.5 * prof["matvec_launches"] / max(a.steps, 1)))))  # (event pool: 1024 samples)
-        s.hip_profile(1, 1)
-        while todo > 0:
-            err1, _, _, _ = admm_steps(be, host, rho, err1, min(chunk, todo), s)
-            roof_samples = s.hip_profile_samples()   # (drains the event pool)
-            todo -= chunk
-        s.hip_profile(0, 1)
+        for target, per, sink in ((0, per_step, roof_samples), (1, fronts_per_step, front_samples)):
+            todo = int(min(4000, np.ceil(a.roofline_samples / per))) + 2
+            chunk = int(max(1, min(todo, 600 // max(1.0, 1.5 * per))))  # (event pool: 1024 samples)
+            s.hip_profile_target(target)
+            s.hip_profile(1, 1)
+            while todo > 0:
+                err1, _, _, _ = admm_steps(be, host, rho, err1, min(chunk, todo), s)
+                sink.extend(s.hip_profile_samples())   # (drains the event pool)
+                todo -= chunk
+            s.hip_profile(0, 1)
+        s.hip_profile_target(0)
         try:
             reps = 200
-            alone_ms = s.hip_ubench(200, reps) / reps
+            alone_ms = s.hip_time_operator(reps) / reps
         except Exception as e:  # noqa: BLE001
             log("rank %d: back-to-back operator run unavailable: %s" % (rank, e))
-        # cones on the k_cw path at the headline shape: the kernels an ADMM iteration actually launches, back to back
-        # (k_front_cw with and without its second visit of the slots, k_wsum, k_spmm_ell)
-        kern_ms = {}
-        for wv, nm in ((30, "k_front_cw"), (31, "k_front_cw_without_second_visit"), (32, "k_wsum"), (2, "k_spmm_ell"), (1, "k_cw")):
-            try:
-                kern_ms[nm] = s.hip_ubench(wv, 200) / 200
-            except Exception:  # noqa: BLE001  (another cone kind / rank: these variants do not apply)
-                kern_ms = {}
-                break
     b_mv = b_cg = 0.0
     for k in range(nloc):
         x, y = s.hip_algorithmic_bytes(k)
@@ -543,8 +541,6 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         # iterations / s at N = 1); strong: ONE problem -> iterations / s
         units = a.steps if strong else world * a.steps
         med = lambda v: float(np.median(v)) if len(v) else None  # noqa: E731
-        mv_ms = med(roof_samples) if roof_samples else (prof["sampled_ms"] / prof["sampled"] if prof["sampled"] else float("nan"))
-        achieved = b_mv / (mv_ms * 1e-3) / 1e9 if mv_ms == mv_ms and mv_ms else None
         cfg_txt = ("%s: %d cone(s) of n=%d r=%d dealt over %d GPU(s) (%d on rank 0)" % (workload, s.nblk_global, info["n"], info["rank"], world, nloc)
                    if strong else
                    "%s: %d block(s) n=%d r=%d, %d constraints/block, NA=%d, NC=%d; one block per GPU"
@@ -576,71 +572,84 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             # start-up cost, untimed: reader + host pre-solve (rank rule, start point), then the device image
             # (patterns, adjacency, slot lists, uploads) built inside lorads_hip_create
             "setup_seconds": {"read_and_presolve_host": t_setup1 - t_setup0, "device_image_in_create": t_setup2 - t_setup1},
-            "roofline": {"bound": "hbm", "kernel": "CG operator application x + A_V^*(A_V x): %s" % op_kernels,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "algorithmic_bytes_per_launch": b_mv, "avg_launch_ms": mv_ms,
-                         "how": "median over %d operator applications, each between two HIP events on the library's stream, "
-                                "untimed pass after the timed region (events add ~1-3 us of marker latency per sample)" % len(roof_samples),
-                         "launches_timed": len(roof_samples),
-                         "event_ms_mean": float(np.mean(roof_samples)) if roof_samples else None,
-                         "event_ms_median": med(roof_samples),
-                         "event_ms_p10_p90": [float(np.percentile(roof_samples, 10)), float(np.percentile(roof_samples, 90))] if roof_samples else None,
-                         "in_timed_region": {"launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"]),
-                                             "event_ms_mean": (prof["sampled_ms"] / prof["sampled"]) if prof["sampled"] else None,
-                                             "event_ms_median": med(samples_timed)},
-                         "operator_alone_back_to_back": None if alone_ms is None else {
-                             "avg_ms": alone_ms, "frac": b_mv / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "what": "200 applications of the live operator back to back between ONE event pair, no scalar "
-                                     "step riding along (kernel boundaries included, no per-sample event latency)"},
-                         "cg_iter_bytes": b_cg,
-                         "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
-                         "traffic": None},
+            "roofline": None,
         }
-        if kern_ms:
-            F = 8.0 * info["n"] * info["rank"]
-            na, nc, m_ = info["na"], info["nc"], info["nrow"]
-            b_rhs = 16.0 * (nc + na) + 8.0 * m_ + 3.0 * F          # assemble S, S V, fuse -rho V and 1 / rho
-            b_half = 2.0 * F + 16.0 * na + 8.0 * m_                # the A(sym(x V^T)) half of an operator application
-            k0 = (kern_ms["k_front_cw"] - kern_ms["k_front_cw_without_second_visit"]) + kern_ms["k_wsum"] + kern_ms["k_spmm_ell"]
-            out["roofline"]["iteration0_form"] = {
-                "what": "the operator application of CG iteration 0 as the timed iterations run it (p_0 = r_0): the constraint "
-                        "weights come from the front's second visit of the slots + k_wsum, then k_spmm_ell; kernels back to back",
-                "avg_ms": k0, "frac": b_mv / (k0 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "general_form_ms": kern_ms["k_cw"] + kern_ms["k_spmm_ell"], "kernels_ms": kern_ms}
-            out["roofline_dominant_kernel"] = {
-                "kernel": "k_front_cw (right-hand side + initial residual + slot contributions of a CG solve; the largest share of an "
-                          "ADMM iteration's kernel time)", "bound": "hbm",
-                "algorithmic_bytes_per_launch": b_rhs + b_mv + b_half, "avg_launch_ms": kern_ms["k_front_cw"],
-                "achieved": (b_rhs + b_mv + b_half) / (kern_ms["k_front_cw"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (b_rhs + b_mv + b_half) / (kern_ms["k_front_cw"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "how": "200 launches back to back between one event pair (lorads_hip_ubench 30); B_rhs + B_mv + half of B_mv, SURVEY 8d"}
+        # ---- roofline of the DOMINANT kernel of the timed iterations, from the launches those iterations make (events on the
+        # library's stream, untimed pass): algorithmic bytes per launch / median launch duration / 8 TB/s
+        F = 8.0 * info["n"] * info["rank"] * nloc
+        na, nc, m_ = info["na"] * nloc, info["nc"] * nloc, info["nrow"] * nloc
+        b_rhs = 16.0 * (nc + na) + 8.0 * m_ + 3.0 * F           # assemble S, S V, fuse -rho V and 1 / rho
+        b_half = 2.0 * F + 16.0 * na + 8.0 * m_                 # the A(sym(x V^T)) half of an operator application
+        stat = lambda v: None if not v else {  # noqa: E731
+            "launches_timed": len(v), "event_ms_median": med(v), "event_ms_mean": float(np.mean(v)),
+            "event_ms_p10_p90": [float(np.percentile(v, 10)), float(np.percentile(v, 90))]}
+        op_ms, fr_ms = med(roof_samples), med(front_samples)
+        cw_front = op_kernels.startswith("k_cw")   # (the one-kernel front also leaves iteration 0's constraint-value contributions)
+        groups = {}
+        if op_ms:
+            groups["cg_operator"] = {
+                "kernel": "CG operator application x + A_V^*(A_V x) as the iterations run it: %s" %
+                          ("k_wsum + k_spmm_ell (iteration 0: the constraint values come out of the front), k_cw + k_spmm_ell otherwise"
+                           if cw_front else op_kernels),
+                "algorithmic_bytes_per_launch": b_mv, "avg_launch_ms": op_ms, "achieved": b_mv / (op_ms * 1e-3) / 1e9,
+                "frac": b_mv / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_per_step": prof["matvec_launches"] / max(a.steps, 1),
+                "events": stat(roof_samples),
+                "alone_back_to_back": None if alone_ms is None else {
+                    "avg_ms": alone_ms, "frac": b_mv / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "what": "200 applications of the live operator (general form) back to back between ONE event pair, no scalar "
+                            "step riding along (kernel boundaries included, no per-sample event latency)"}}
+        if fr_ms:
+            fb = b_rhs + b_mv + (b_half if cw_front else 0.0)
+            groups["solve_front"] = {
+                "kernel": ("k_front_cw: rhs = V - (C + sum M1_i A_i) V / rho, initial residual, and the slot contributions of "
+                           "A(sym(r0 V^T)) (iteration 0's constraint values)" if cw_front else
+                           "front of a CG solve: right-hand side and initial residual in one pass (k_spmm2<FRONT> / k_sval + k_spmm2 + operator)"),
+                "algorithmic_bytes_per_launch": fb, "avg_launch_ms": fr_ms, "achieved": fb / (fr_ms * 1e-3) / 1e9,
+                "frac": fb / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_per_step": fronts_per_step,
+                "bytes": "B_rhs + B_mv%s (SURVEY 8d)" % (" + half of B_mv" if cw_front else ""), "events": stat(front_samples)}
+        share = {k: g["avg_launch_ms"] * g["launches_per_step"] for k, g in groups.items()}
+        dom = max(share, key=share.get) if share else None
+        if dom:
+            g = groups[dom]
+            out["roofline"] = {"bound": "hbm", "kernel": g["kernel"], "achieved": g["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": g["frac"], "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
+                               "avg_launch_ms": g["avg_launch_ms"], "traffic": None,
+                               "dominant": "%s: %.1f %% of the step (%.1f us x %.1f launches of %.1f us)" %
+                                           (dom, 100 * share[dom] / (1e3 * elapsed / a.steps) if elapsed else 0.0, 1e3 * g["avg_launch_ms"],
+                                            g["launches_per_step"], 1e6 * elapsed / a.steps),
+                               "how": "median over %d launches, each between two HIP events on the library's stream, in an untimed pass "
+                                      "after the timed region that runs the same iterations (events add ~1-3 us of marker latency per "
+                                      "sample); the kernel group with the largest share of the step" % g["events"]["launches_timed"],
+                               "in_timed_region": {"launches_timed": int(prof["sampled"]), "launches_total": int(prof["matvec_launches"])},
+                               "cg_iter_bytes": b_cg,
+                               "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS),
+                               "groups": groups}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                               "traffic": None, "how": "no launches were timed (--roofline-samples 0)", "cg_iter_bytes": b_cg,
+                               "cg_iter_frac_of_hbm": (b_cg * cg_iters / world / elapsed / 1e9 / HBM_PEAK_GBS)}
         # committed rocprofv3 / PMC summaries of this same command: replayed ONLY when their stamp matches the HIP sources
         # of this run (a profile of older kernels is not this run's evidence)
-        tr, tsrc = traffic_from_profiles(workload)
-        pms, psrc = rocprof_from_profiles(workload, op_kernels)
-        for val, src, key in ((tr, tsrc, "traffic"), (pms, psrc, "rocprofv3")):
-            if val is None:
-                continue
-            ok, head = profile_stamp_ok(src)
-            if not ok:
-                out["roofline"][key + "_source"] = "%s is stale (HIP sources changed since it was collected): not replayed" % src
-                continue
-            if key == "traffic":
-                out["roofline"]["traffic"] = val
-                out["roofline"]["traffic_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
-            else:
-                out["roofline"]["rocprofv3_avg_launch_ms"] = val
-                out["roofline"]["rocprofv3_frac"] = b_mv / (val * 1e-3) / 1e9 / HBM_PEAK_GBS
-                out["roofline"]["rocprofv3_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
-        if op_kernels == "k_op_diag":
-            # Max-Cut-type cones: from iteration 1 on the operator kernel also forms the direction p = r + beta p of that
-            # iteration (reads r and p, writes p: 3 more factor passes), so its launches move more than the operator's
-            # algorithmic bytes; priced here for the launches that carry it (most of them)
-            fused = b_mv + 3.0 * 8.0 * info["n"] * info["rank"] * nloc
-            out["roofline"]["with_fused_direction_update"] = {
-                "bytes_per_launch": fused,
-                "frac_events": fused / (mv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if achieved else None}
+        if dom:
+            pm, tsrc = traffic_from_profiles(workload)
+            tr = (pm or {}).get("solve_front" if dom == "solve_front" else "cg_operator_application", {}).get("traffic_bytes")
+            dom_kernels = ("k_front_cw" if cw_front else "k_spmm2") if dom == "solve_front" else \
+                          ("k_wsum+k_spmm_ell" if cw_front else op_kernels)
+            pms, psrc = rocprof_from_profiles(workload, dom_kernels)
+            for val, src, key in ((tr, tsrc, "traffic"), (pms, psrc, "rocprofv3")):
+                if val is None:
+                    continue
+                ok, head = profile_stamp_ok(src)
+                if not ok:
+                    out["roofline"][key + "_source"] = "%s is stale (HIP sources changed since it was collected): not replayed" % src
+                    continue
+                if key == "traffic":
+                    out["roofline"]["traffic"] = val
+                    out["roofline"]["traffic_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
+                else:
+                    out["roofline"]["rocprofv3_avg_launch_ms"] = val
+                    out["roofline"]["rocprofv3_frac"] = out["roofline"]["algorithmic_bytes_per_launch"] / (val * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    out["roofline"]["rocprofv3_source"] = "%s (committed, collected at %s from these sources; not measured in this run)" % (src, head)
         if world == 1 and with_cpu:
             try:
                 cb = cpu_baseline(path, tlr, rho, state_file, a.cpu_budget, log, n_max=info["n"],

@@ -17,13 +17,19 @@ extern "C" {
  *                sampled matvec launches, sampled matvec ms, spmm sampled launches, spmm sampled ms} */
 int lorads_hip_profile(lorads_hip_ctx *ctx, int32_t enable, int32_t sample_every);
 int lorads_hip_profile_read(lorads_hip_ctx *ctx, double stats[8]);
+/* what the next profiling windows time, one launch group in `sample_every`: 0 = CG operator applications (default), 1 = the front of
+ * a CG solve (right-hand side + initial residual: k_front_cw / k_spmm2<FRONT>).  The events bracket the launches the iteration makes
+ * anyway; nothing is launched differently because it is timed. */
+int lorads_hip_profile_target(lorads_hip_ctx *ctx, int32_t target);
 /* the individual samples (milliseconds per timed operator application) behind stats[4..5], oldest first: copies
  * min(cap, count) of them to out and returns the count in *n (for a median / spread next to the mean) */
 int lorads_hip_profile_samples(lorads_hip_ctx *ctx, double *out, int32_t cap, int32_t *n);
-/* Diagnostic (profiles/tools/ubench.py): `reps` back-to-back launches of kernel variant `which` on cone 0, elapsed
- * milliseconds of all of them.  Overwrites the CG scratch vectors; the factors are left alone.
- * which = 200: the live CG operator of cone 0 (whatever kernels apply it), applied to the CG direction buffer, no
- * scalar step riding along -- "the operator alone", boundaries between consecutive launches included. */
+/* `reps` applications of the live CG operator of cone 0 (whatever kernels apply it) to the CG direction buffer, back to back
+ * between one event pair, no scalar step riding along -- "the operator alone", boundaries between consecutive launches included;
+ * elapsed milliseconds of all of them.  Overwrites the CG scratch vectors; the factors are left alone. */
+int lorads_hip_time_operator(lorads_hip_ctx *ctx, int32_t reps, double *ms);
+/* DEVELOPMENT build only (liblorads_hip_dev.so; profiles/tools/ubench.py): `reps` back-to-back launches of kernel variant `which`
+ * on cone 0, elapsed milliseconds of all of them.  The product library does not export it. */
 int lorads_hip_ubench(lorads_hip_ctx *ctx, int32_t which, int32_t reps, double *ms);
 /* algorithmic bytes of one CG operator application / one CG iteration of block blk */
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *ctx, int32_t blk, double *bytes_matvec, double *bytes_cg_iter);

@@ -335,6 +335,9 @@ enum { DIR_BETA = 1, DIR_RESTART = 2 };
 enum { CV_SET = 0, CV_ADD = 1, CV_DELTA = 2 };
 
 #include "kernels.inc"
+#ifdef LORADS_DEV_BUILD
+#include "dev_kernels.inc"
+#endif
 
 // ------------------------------------------------------------------ host side
 template <typename T>
@@ -567,6 +570,8 @@ struct lorads_hip_ctx {
     bool opt_gram = true;     // LORADS_LBFGS_GRAM=0: sharded direction by the sequential recursion, one collective per dot
     // profiling
     int prof = 0, prof_every = 8;
+    int prof_target = 0;      // what a profiling window times: 0 = CG operator applications, 1 = solve fronts (lorads_hip_profile_target)
+    long n_front = 0;
     long n_sweeps = 0;        // ADMM sweeps run so far (cadence of the exact constraint refresh, see constr_by_recurrence)
     long n_matvec = 0, n_cg_it = 0, n_solves = 0, n_samp = 0, n_samp_spmm = 0, n_resume = 0;
     double ms_samp = 0, ms_samp_spmm = 0;
@@ -1269,8 +1274,15 @@ int lorads_hip_profile(lorads_hip_ctx *c, int32_t enable, int32_t every) {
         for (auto &e : c->ev_pool) HC(hipEventCreate(&e));
     }
     c->n_matvec = c->n_cg_it = c->n_solves = c->n_samp = c->n_samp_spmm = c->n_resume = 0;
+    c->n_front = 0;
     c->ms_samp = c->ms_samp_spmm = 0;
     c->samp_ms.clear();
+    return 0;
+}
+
+int lorads_hip_profile_target(lorads_hip_ctx *c, int32_t target) {
+    if (target != 0 && target != 1) return fail_msg("profile_target: 0 (operator applications) or 1 (solve fronts)");
+    c->prof_target = target;
     return 0;
 }
 
@@ -1298,171 +1310,22 @@ int lorads_hip_profile_read(lorads_hip_ctx *c, double s[8]) {
     return 0;
 }
 
-// Diagnostic: `reps` back-to-back launches of one kernel variant on cone 0 between two events (ms for all of them);
-// under rocprofv3 every variant shows up under its own name.  Inputs are the cone's U and V, outputs go to the CG
-// scratch vectors.  Only for the shape of the headline (r = 40); profiles/tools/ubench.py drives it.
-int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms) {
-    if (c->nb < 1) return fail_msg("ubench: no cone");
+// `reps` applications of the live CG operator of cone 0, back to back between ONE event pair, nothing riding along (milliseconds for
+// all of them): bench.py's operator_alone_back_to_back
+int lorads_hip_time_operator(lorads_hip_ctx *c, int32_t reps, double *ms) {
+    if (c->nb < 1) return fail_msg("time_operator: no cone");
     Block &B = c->blk[0];
-    if (which == 200) { // the live operator of cone 0, back to back, nothing riding along
-        flush_pending(c);
-        hipEvent_t e0, e1;
-        HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-        const int prof0 = c->prof;
-        c->prof = 0;
-        HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
-        hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
-        const bool tv = B.t_uv_valid;
-        for (int it = -3; it < reps; ++it) {
-            if (it == 0) HC(hipEventRecord(e0, c->stream));
-            apply_operator(c, B, c->V + B.off, c->cp + B.off, OP_CG, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
-        }
-        HC(hipEventRecord(e1, c->stream));
-        HC(hipEventSynchronize(e1));
-        float f = 0;
-        HC(hipEventElapsedTime(&f, e0, e1));
-        *ms = f;
-        hipEventDestroy(e0); hipEventDestroy(e1);
-        c->prof = prof0;
-        c->n_matvec -= reps + 3;
-        B.t_uv_valid = (B.use_cw || B.diag_only || B.entry_only) ? tv : false; // (those write w_op only; the others overwrite the pair dots)
-        return 0;
-    }
-    if (which >= 100) { // single-entry cones (matrix completion): the whole-operator kernels, any rank
-        if (!B.entry_only) return fail_msg("ubench: variants >= 100 need a single-entry cone");
-        hipEvent_t e0, e1;
-        HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-        if (which != 100 && which != 120 && which != 121) return fail_msg("ubench: unknown variant");
-        const Shape shp = shape_for(B.r);
-        for (int it = -3; it < reps; ++it) {
-            if (it == 0) HC(hipEventRecord(e0, c->stream));
-            if (which == 100)
-                op_entry(c, B, c->V + B.off, OP_CG, c->U + B.off, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
-            else // 120 / 121: pure gathers of this cone's rows (the first na slots of its neighbour list: all row numbers < n)
-                SHAPE_DISPATCH(shp, LAUNCH((k_gather_probe<LG_, V2_, NS_>), nblocks_for((size_t)B.n, TPB / shp.lg), B.n, 16, B.pa.adj_col,
-                                           B.na, c->V + B.off, which == 121 ? c->U + B.off : (const double *)nullptr, B.r,
-                                           c->cQ + B.off));
-        }
-        HC(hipEventRecord(e1, c->stream));
-        HC(hipEventSynchronize(e1));
-        float f = 0;
-        HC(hipEventElapsedTime(&f, e0, e1));
-        *ms = f;
-        hipEventDestroy(e0); hipEventDestroy(e1);
-        return 0;
-    }
-    if (B.r != 40 || !B.use_cw || !B.cell_w || !B.pu.S2) return fail_msg("ubench: needs a k_cw cone of rank 40");
-    const double *U = c->U + B.off, *V = c->V + B.off;
-    double *Q = c->cQ + B.off, *r = c->cr + B.off, *p = c->cp + B.off, *rhs = c->rhs + B.off;
-    const size_t len = (size_t)B.n * B.r;
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
-    HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
+    flush_pending(c);
     hipEvent_t e0, e1;
     HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-    const int grow = nblocks_for((size_t)B.n, TPB / 8), gcw = nblocks_for((size_t)B.nrow, TPB / 64);
-    // 40-44: the column-sliced experiment (see k_cw_sliced): sliced copies of x, V, an output and the slice parts of the weights
-    double *Xs = nullptr, *Vs = nullptr, *Os = nullptr, *wpart = nullptr, *wtot = nullptr;
-    if (which >= 40 && which <= 44) {
-        if (B.ca_ell <= 0 || B.ca_ell > 16 || (B.cell_w != 8 && B.cell_w != 16)) return fail_msg("ubench 40-44: needs fixed-width lists (<= 16 entries, 8 or 16 slots)");
-        if (dalloc(&Xs, len) || dalloc(&Vs, len) || dalloc(&Os, len) || dalloc(&wpart, (size_t)B.nrow * 8) || dalloc(&wtot, (size_t)B.nrow)) return 1;
-        LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, U, Xs);
-        LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, V, Vs);
-    }
-    const int gcs = 8 * nblocks_for((size_t)B.nrow, TPB / 16), gss = 8 * nblocks_for((size_t)B.n, TPB / 8);
-#define SPMM_SL(W_)                                                                                                                 \
-    do {                                                                                                                            \
-        if (B.cell_w == 8) LAUNCH((k_spmm_sliced<5, 8>), gss, B.n, B.cell_col, B.cell_con, B.cell_a, W_, Vs, Xs, Os);               \
-        else LAUNCH((k_spmm_sliced<5, 16>), gss, B.n, B.cell_col, B.cell_con, B.cell_a, W_, Vs, Xs, Os);                            \
-    } while (0)
-    for (int it = -3; it < reps; ++it) { // three warm-up launches
+    const int prof0 = c->prof;
+    c->prof = 0;
+    HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
+    const bool tv = B.t_uv_valid;
+    for (int it = -3; it < reps; ++it) {
         if (it == 0) HC(hipEventRecord(e0, c->stream));
-        switch (which) {
-        case 0: LAUNCH((k_cw<8, true, 3>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op, (double *)nullptr,
-                       (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{}); break;
-        case 1: LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
-                       (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{}); break;
-        case 2:
-            if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
-                                      B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q,
-                                      part_slot(c, 0), NOGUARD);
-            else LAUNCH((k_spmm_ell<8, true, 3, 16>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col, B.cell_con,
-                        B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
-            break;
-        case 30: case 31: { // the one-kernel front (31: without the second visit of the slots), weights of a plain W_ADMM front
-            if (!B.front_cw) return fail_msg("ubench: cone without the one-kernel front's data");
-            FrontCwArgs A{};
-            A.fc_ptr = B.fc_ptr; A.fc_col = B.fc_col; A.fc_val = B.fc_val; A.sl_ptr = B.cadj_ptr; A.sl_col = B.cadj_col; A.sl_con = B.cadj_con;
-            A.sl_a = B.cadj_a; A.ell_col = B.cell_col; A.ell_con = B.cell_con; A.ell_a = B.cell_a; A.ell_dst = B.cell_dst; A.sl_dst = B.cadj_dst;
-            A.csum = c->csum; A.b = c->b; A.lambda = c->lambda; A.cv = B.cv; A.w_uv = B.w_op;
-            A.row_idx = B.row_idx_identity ? nullptr : B.row_idx; A.rho = 1.0; A.wmode = W_ADMM;
-            A.contrib = which == 30 ? B.w_contrib : (double *)nullptr;
-            if (B.cell_w == 8) LAUNCH((k_front_cw<3, 8>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
-            else LAUNCH((k_front_cw<3, 16>), grow, B.n, A, V, B.r, U, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD, Deferred{});
-        } break;
-        case 40: LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart); break;
-        case 41: SPMM_SL((const double *)B.w_op); break;
-        case 42: LAUNCH((k_to_sliced<5>), grid1d(len), B.n, B.r, U, Xs); break;
-        case 43: // the whole sliced operator application
-            LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart);
-            LAUNCH(k_wsum8, nblocks_for((size_t)B.nrow, TPB), B.nrow, (const double *)wpart, wtot);
-            SPMM_SL((const double *)wtot);
-            break;
-        case 44: // ... with a streaming kernel over 19 MB in between (k_cg_update's traffic): the slices do not survive in L2
-            LAUNCH((k_cw_sliced<5>), gcs, B.nrow, B.ca_ell, B.ca_row, B.ca_col, B.ca_val, Xs, Vs, B.n, wpart);
-            LAUNCH(k_wsum8, nblocks_for((size_t)B.nrow, TPB), B.nrow, (const double *)wpart, wtot);
-            SPMM_SL((const double *)wtot);
-            LAUNCH(k_cg_update<true>, 512, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
-                   (const double *)nullptr, 0, c->st_shadow);
-            break;
-        case 45: // the row-major operator with the same streaming kernel in between (the pair to 44)
-            LAUNCH((k_cw<4, true, 5, true>), gcw, B.nrow, B.a_ptr, B.ca_row, B.ca_val, B.ca_col, U, V, B.r, 1.0, B.w_op,
-                   (double *)nullptr, (int)CV_SET, B.row_idx, (double *)nullptr, NOGUARD, B.ca_ell, InitArgs{}, ResArgs{});
-            if (B.cell_w == 8) LAUNCH((k_spmm_ell<8, true, 3, 8>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
-                   B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
-            else LAUNCH((k_spmm_ell<8, true, 3, 16>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, B.cadj_a, B.cell_col,
-                   B.cell_con, B.cell_a, (const double *)B.w_op, V, B.r, (int)OP_CG, U, (const double *)nullptr, Q, part_slot(c, 0), NOGUARD);
-            LAUNCH(k_cg_update<true>, 512, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
-                   (const double *)nullptr, 0, c->st_shadow);
-            break;
-        case 32: LAUNCH(k_wsum, nblocks_for((size_t)B.nrow, TPB / 8), B.nrow, B.cs_w, (const double *)B.w_contrib, B.w_op, NOGUARD, InitArgs{}, 0, DS(0.0),
-                        c->m, (const double *)c->b, (const double *)c->csum, c->lambda); break;
-        case 3: LAUNCH((k_spmm<8, true, 3, true>), grow, B.n, B.cadj_ptr, B.cadj_col, B.cadj_con, (const double *)B.w_op, V, B.r,
-                       (int)OP_CG, U, (const double *)nullptr, 0.0, Q, part_slot(c, 0), NOGUARD, (const double *)nullptr, B.cadj_a); break;
-        case 4: LAUNCH((k_spmm2<8, true, 3, true>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)B.pu.S2, V,
-                       B.r, 0, U, (const double *)nullptr, 1.0, r, rhs, part_slot(c, 0), part_slot(c, 1), NOGUARD,
-                       (const double *)nullptr); break;
-        case 5: LAUNCH((k_spmm2<8, true, 3, false>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_dyn, B.pu.adj_sval, B.pu.S, (const double *)nullptr, V,
-                       B.r, (int)OP_RHS, (const double *)nullptr, (const double *)nullptr, 1.0, rhs, (double *)nullptr, part_slot(c, 1),
-                       (double *)nullptr, NOGUARD, (const double *)nullptr); break;
-        case 6: case 7: case 8: case 9: { // k_cg_update with 2048 / 1024 / 512 / 256 workgroups (alpha = 0 / 1: arrays stay put)
-            const int gv = 2048 >> (which - 6);
-            LAUNCH(k_cg_update<true>, gv, len, c->st, part_slot(c, 0), 625, Q, rhs, p, r, part_slot(c, 2), NOGUARD, (double *)nullptr,
-                   (const double *)nullptr, 0, c->st_shadow);
-        } break;
-        case 20: case 21: case 22: case 23: case 24: {
-            // pure row gathers (every index is a row number < n: cadj_col holds neighbour rows; null = ascending rows)
-            // 20-22: 64 rows per 8-lane group, 40000 groups = 0.82 GB of 320-byte rows (deep queues, long kernel)
-            // 23-24: 16 rows per group, one group per row of the cone = the shape of the solve front (short kernel)
-            const bool shortk = which >= 23;
-            const int ngroups = shortk ? B.n : 40000, per = shortk ? 16 : 64;
-            const double *two = (which == 21 || which == 24) ? U : (const double *)nullptr; // rows of x and V in turn
-            const int *idx = which == 22 ? (const int *)nullptr : B.cadj_col;
-            const int nidx = which == 22 ? B.n : B.cadj_ptr_host_n;
-            if (nidx <= 0) return fail_msg("ubench: empty index list");
-            LAUNCH((k_gather_probe<8, true, 3>), nblocks_for((size_t)ngroups, TPB / 8), ngroups, per, idx, nidx, V, two, B.r, Q);
-        } break;
-        case 25: LAUNCH((k_gather_probe2<8, true, 3, 0>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
-        case 26: LAUNCH((k_gather_probe2<8, true, 3, 1>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
-        case 27: LAUNCH((k_gather_probe2<8, true, 3, 3>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
-        case 28: LAUNCH((k_gather_probe2<8, true, 3, 7>), grow, B.n, B.pu.adj_ptr, B.pu.adj_col, B.pu.adj_e, B.pu.S, V, B.r, Q); break;
-        case 10: case 13: case 14: // k_obj on at most 1024 / 2048 / 4096 workgroups
-            LAUNCH((k_obj<8, true, 3>), std::min(nblocks_for((size_t)B.nc, TPB / 8), which == 10 ? 1024 : which == 13 ? 2048 : 4096), B.nc,
-                   B.c_row, B.c_col, B.c_val, U, U, B.r, part_slot(c, 4), NOGUARD); break;
-        case 11: LAUNCH(k_sval, std::max(1, nblocks_for((size_t)B.pu.ne, TPB)), B.pu.ne, B.pu.e_ptr, B.pu.e_con, B.pu.e_val, B.pu.cbase,
-                        (int)W_COMPACT, WArgs{B.w_op, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0}, B.pu.S, NOGUARD,
-                        (CGState *)nullptr, 0, (const double *)B.w_op, B.pu.S2); break;
-        default: return fail_msg("ubench: unknown variant");
-        }
+        apply_operator(c, B, c->V + B.off, c->cp + B.off, OP_CG, nullptr, c->cQ + B.off, part_slot(c, 0), NOGUARD);
     }
     HC(hipEventRecord(e1, c->stream));
     HC(hipEventSynchronize(e1));
@@ -1470,10 +1333,15 @@ int lorads_hip_ubench(lorads_hip_ctx *c, int32_t which, int32_t reps, double *ms
     HC(hipEventElapsedTime(&f, e0, e1));
     *ms = f;
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(Xs); hipFree(Vs); hipFree(Os); hipFree(wpart); hipFree(wtot);
-    invalidate_t(c);
+    c->prof = prof0;
+    c->n_matvec -= reps + 3;
+    B.t_uv_valid = (B.use_cw || B.diag_only || B.entry_only) ? tv : false; // (those write w_op only; the others overwrite the pair dots)
     return 0;
 }
+
+#ifdef LORADS_DEV_BUILD
+#include "dev.inc"
+#endif
 
 int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");

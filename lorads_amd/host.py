@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
+DEV_LIB = os.path.join(LIB_DIR, "liblorads_hip_dev.so")   # development build: the product library + lorads_hip_ubench (csrc/Makefile `dev`)
 
 PAIR_RR, PAIR_UV = 0, 1
 MAT_R, MAT_U, MAT_V, MAT_GRAD = 0, 1, 2, 3
@@ -341,6 +342,7 @@ class Session:
         library or a GPU is missing: the product has no other backend."""
         st = BackendStruct()
         path = libpath or os.path.join(LIB_DIR, "liblorads_hip.so")
+        self._hip_path = path
         rc = self.lib.lrd_hip_backend_create(self.problem_ptr(), lbfgs_len, os.fsencode(path), C.byref(st))
         if rc != 0:
             raise RuntimeError("HIP backend unavailable (code %d): %s -- the product has no CPU fallback" % (rc, path))
@@ -349,12 +351,11 @@ class Session:
     # ---- measurement hooks of the HIP library (bench.py)
     def _hip(self):
         if getattr(self, "_hiplib", None) is None:
-            lib = C.CDLL(os.path.join(LIB_DIR, "liblorads_hip.so"))
+            lib = C.CDLL(getattr(self, "_hip_path", None) or os.path.join(LIB_DIR, "liblorads_hip.so"))
             lib.lorads_hip_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
             lib.lorads_hip_profile_read.argtypes = [C.c_void_p, _dp]
             lib.lorads_hip_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
             lib.lorads_hip_sync.argtypes = [C.c_void_p]
-            lib.lorads_hip_ubench.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
             lib.lorads_hip_operator_kind.argtypes = [C.c_void_p, C.c_int, _ip]
             lib.lorads_hip_stream.restype = C.c_void_p
             lib.lorads_hip_stream.argtypes = [C.c_void_p]
@@ -368,6 +369,12 @@ class Session:
     def hip_profile(self, enable, sample_every=8):
         lib, ctx = self._hip()
         _check(lib.lorads_hip_profile(ctx, int(enable), int(sample_every)), "profile")
+
+    def hip_profile_target(self, target):
+        """0: time CG operator applications (default), 1: time solve fronts"""
+        lib, ctx = self._hip()
+        lib.lorads_hip_profile_target.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.lorads_hip_profile_target(ctx, int(target)), "profile_target")
 
     def hip_profile_read(self):
         lib, ctx = self._hip()
@@ -385,9 +392,24 @@ class Session:
         _check(lib.lorads_hip_profile_samples(ctx, buf, cap, C.byref(n)), "profile_samples")
         return [buf[i] for i in range(min(cap, n.value))]
 
-    def hip_ubench(self, which, reps):
-        """milliseconds of `reps` back-to-back launches of kernel variant `which` (diagnostic, see lorads_hip.h)"""
+    def hip_time_operator(self, reps):
+        """milliseconds of `reps` applications of the live CG operator of cone 0, back to back (see lorads_hip_dev.h)"""
         lib, ctx = self._hip()
+        ms = C.c_double()
+        lib.lorads_hip_time_operator.argtypes = [C.c_void_p, C.c_int, _dp]
+        rc = lib.lorads_hip_time_operator(ctx, int(reps), C.byref(ms))
+        if rc:
+            lib.lorads_hip_last_error.restype = C.c_char_p
+            raise RuntimeError("time_operator: %s" % (lib.lorads_hip_last_error() or b"?").decode())
+        return ms.value
+
+    def hip_ubench(self, which, reps):
+        """milliseconds of `reps` back-to-back launches of kernel variant `which`: DEVELOPMENT build only -- the session must have
+        been attached with attach_hip(libpath=host.DEV_LIB) (profiles/tools/ubench.py)"""
+        lib, ctx = self._hip()
+        if not hasattr(lib, "lorads_hip_ubench"):
+            raise RuntimeError("ubench: not in the product library (attach the session to host.DEV_LIB)")
+        lib.lorads_hip_ubench.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         ms = C.c_double()
         rc = lib.lorads_hip_ubench(ctx, int(which), int(reps), C.byref(ms))
         if rc:

@@ -1,5 +1,5 @@
 """How the hot path scales with the cone's size: the two headline families (random sparse A_i as cfg3b, Max-Cut as cfg3a) at rank 40
-from n = 2500 to n = 80000 -- ADMM iterations / s, CG iterations / s, the live CG operator back to back (lorads_hip_ubench 200)
+from n = 2500 to n = 80000 -- ADMM iterations / s, CG iterations / s, the live CG operator back to back (lorads_hip_time_operator)
 against the algorithmic bytes of SURVEY 8d.  Small cones are bound by the ~1.7 us a kernel boundary costs (10 launches per
 iteration), large ones by the rate at which the fabric delivers gathered rows.  usage: size_sweep.py [steps]"""
 import math
@@ -40,7 +40,7 @@ for fam in ("rand", "maxcut"):
         err1, cg, _, _ = bench.admm_steps(be, host, rho, err1, steps, s)
         s.hip_sync()
         el = time.perf_counter() - t0
-        op_ms = s.hip_ubench(200, 200) / 200
+        op_ms = s.hip_time_operator(200) / 200
         mv, _ = s.hip_algorithmic_bytes(0)
         info = s.block_info(0)
         gs = s.hip_graph_stats()

@@ -14,10 +14,6 @@ NAMES = {0: "k_cw<8 lanes, two entries per trip>", 1: "k_cw<4 lanes, one trip>",
          6: "k_cg_update 2048 wg", 7: "k_cg_update 1024 wg", 8: "k_cg_update 512 wg", 9: "k_cg_update 256 wg",
          30: "k_front_cw (rhs + initial residual + slot contributions)", 31: "k_front_cw without the second visit of the slots",
          32: "k_wsum (constraint weights from the contributions)",
-         40: "EXPERIMENT column-sliced factors: k_cw_sliced (slice parts of the constraint values)",
-         41: "EXPERIMENT column-sliced factors: k_spmm_sliced (8-slot list)", 42: "EXPERIMENT: re-layout of one factor into 8 column slices",
-         43: "EXPERIMENT sliced operator application: k_cw_sliced + k_wsum8 + k_spmm_sliced",
-         44: "EXPERIMENT sliced operator application + k_cg_update in between (19 MB streamed)",
          45: "row-major operator application (k_cw + k_spmm_ell) + k_cg_update in between",
          10: "k_obj", 11: "k_sval (two images)", 13: "k_obj, up to 2048 workgroups", 14: "k_obj, up to 4096 workgroups",
          20: "gather probe: 2.56 M random 320-B rows of V (6.4 MB table)", 21: "gather probe: rows of x and V in turn (12.8 MB)",
@@ -44,7 +40,7 @@ def main():
     if workload == "matcomp50000":
         s.set_params(dyrankLevel=0)   # (r = 60 as BASELINE cfg5 names it; with rank growth phase 1 ends at r = 90)
     s.prepare(1, 0)
-    s.attach_hip()
+    s.attach_hip(libpath=host.DEV_LIB)   # (lorads_hip_ubench lives in the development build only)
     s.alm()
     s.alm_to_admm()
     s.be.init_constr(host.PAIR_UV)
