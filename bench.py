@@ -51,19 +51,17 @@ def traffic_from_profiles(workload):
 
 
 def rocprof_from_profiles(workload, op_kernels):
-    """Average duration (ms) of one CG operator application according to the committed rocprofv3 --kernel-trace --stats
-    summary of this same command (profiles/*_<workload>_kernel_stats.csv): sum over the operator's kernels of the
-    average of their most-called instantiation.  None if there is no such file."""
+    """Average duration (ms) of one launch group (the kernels named in op_kernels, e.g. "k_front_cw" or "k_wsum+k_spmm_ell") according
+    to the committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/*_<workload>_kernel_stats.csv): sum over
+    the kernels of the average of their most-called instantiation.  None if there is no such file."""
     import csv
     import re
     pdir = os.path.join(ROOT, "profiles")
     best = None
-    # (the run profiled with the operator in its general form -- LORADS_FRONT_CW=0: every application is k_cw + k_spmm_ell, as
-    # the roofline pass times it -- where the round has one; the default run's k_cw launches are mostly the evaluation's)
-    for suffix in ("_%s_kernel_stats.csv" % workload, "_general_form_%s_kernel_stats.csv" % workload):
-        for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-            if f.endswith(suffix) and (best is None or f.split("_")[0] >= os.path.basename(best).split("_")[0]):
-                best = os.path.join(pdir, f)
+    # (the newest round's profile of the DEFAULT run: the kernels as the timed iterations launch them)
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_%s_kernel_stats.csv" % workload) and "general_form" not in f:
+            best = os.path.join(pdir, f)
     if not best:
         return None, None
     names = re.findall(r"k_\w+", op_kernels)

@@ -45,15 +45,19 @@ def test_profile_stamp_gates_the_replay(tmp_path, monkeypatch):
     assert bench.profile_stamp_ok("profiles/r07_pmc_rand20000.json")[0] is False           # other sources: stale
     (prof / "r07_stamp.json").write_text(json.dumps({"hip_source_sha256": h, "git_head": "abc"}))
     assert bench.profile_stamp_ok("profiles/r07_pmc_rand20000.json") == (True, "abc")
-    assert bench.traffic_from_profiles("rand20000") == (1.0, os.path.join("profiles", "r07_pmc_rand20000.json"))
+    assert bench.traffic_from_profiles("rand20000") == ({"cg_operator_application": {"traffic_bytes": 1.0}},
+                                                        os.path.join("profiles", "r07_pmc_rand20000.json"))
 
 
-def test_operator_profile_prefers_the_general_form_run(tmp_path, monkeypatch):
+def test_kernel_profile_is_the_default_runs(tmp_path, monkeypatch):
+    """the committed rocprofv3 summary that is replayed is the one of the default run (the kernels as the timed iterations launch them)"""
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     hdr = '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
-    (prof / "r07_rand20000_kernel_stats.csv").write_text(hdr + '"void k_cw<4>(int)",60,1,5000.0,1,1,1,0\n"void k_spmm_ell<8>(int)",110,1,9000.0,1,1,1,0\n')
+    (prof / "r07_rand20000_kernel_stats.csv").write_text(hdr + '"void k_wsum(int)",110,1,5000.0,1,1,1,0\n"void k_spmm_ell<8>(int)",110,1,9000.0,1,1,1,0\n"void k_front_cw<3, 16>(int)",110,1,27000.0,1,1,1,0\n')
     (prof / "r07_general_form_rand20000_kernel_stats.csv").write_text(hdr + '"void k_cw<4>(int)",169,1,12000.0,1,1,1,0\n"void k_spmm_ell<8>(int)",110,1,10000.0,1,1,1,0\n')
-    ms, src = bench.rocprof_from_profiles("rand20000", "k_cw+k_spmm_ell")
-    assert src.endswith("r07_general_form_rand20000_kernel_stats.csv") and np.isclose(ms, 0.022)
+    ms, src = bench.rocprof_from_profiles("rand20000", "k_wsum+k_spmm_ell")
+    assert src.endswith("r07_rand20000_kernel_stats.csv") and np.isclose(ms, 0.014)
+    ms, src = bench.rocprof_from_profiles("rand20000", "k_front_cw")
+    assert np.isclose(ms, 0.027)
