@@ -139,3 +139,138 @@ def test_native_rccl_hook_whole_solves_on_one_rank(built):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert len(lines) == 8 and all(" rccl-native " in ln and " ok " in ln for ln in lines), lines
     assert sum(" separable " in ln for ln in lines) == 4
+
+
+def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q):
+    """one rank of test_fullsize_sharded_iterations...: the cones dealt to it, the single-process state loaded into them, `its`
+    ADMM iterations with the cross-rank sums through the device-buffer all-reduce hook"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bench
+    from lorads_amd import host
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    s = host.Session.open(path)
+    s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+    s.prepare(world, rank, separable=separable)
+    s.attach_hip()
+    try:
+        mode, seen = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
+        assert seen == world
+        st = np.load(statefile)
+        for j in range(s.nblk):                 # cones are dealt round robin: local cone j is cone rank + j * world of the file
+            k = rank + j * world
+            s.be.set_mat(host.MAT_U, j, st["U%d" % k])
+            s.be.set_mat(host.MAT_V, j, st["V%d" % k])
+        s.be.set_vec(host.VEC_LAMBDA, st["lam"][np.asarray(s.constraint_map)])
+        rho = float(st["rho"])
+        be = s.be
+        be.init_constr(host.PAIR_UV)
+        be.cal_obj(host.PAIR_UV)
+        e0 = be.update_dimacs(host.PAIR_UV)
+        e1, cg, p1, d1 = bench.admm_steps(be, host, rho, e0, its, s)
+        s.hip_sync()
+        Us = {"U%d" % (rank + j * world): be.get_mat(host.MAT_U, j) for j in range(s.nblk)}
+        q.put((rank, dict(err0=e0, err1=e1, cg=int(cg), pObj=p1, dObj=d1, nblk_local=s.nblk, m_local=s.m, separable=bool(s.separable),
+                          mode=mode, U=Us)))
+    finally:
+        s.close()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,separable", [(2, True), (4, True), (2, False), (4, False)])
+def test_fullsize_sharded_iterations_match_one_process_and_the_reference(built, world, separable):
+    """BASELINE cfg4 at full size -- 16 cones of n = 4000, 64000 constraints -- dealt over 2 and 4 ranks (processes on the one card,
+    device-buffer all-reduce hook), in the scalars-only form of separable shards and in the m-vector form: 20 ADMM iterations from
+    the SINGLE-PROCESS phase-1 state.  Block-separable constraints: the ranks' Jacobi sweep is the reference's Gauss-Seidel sweep
+    (SURVEY.md 8e), so the sharded run must reproduce the single-process run iterate for iterate -- same CG iteration count, same
+    objectives and factors up to the order of the cross-rank sums -- and the compiled reference's 20 iterations from the same state
+    (oracle/_ref/ref_driver admmbench) to 1e-10."""
+    import subprocess
+    import numpy as np
+    import bench
+    from lorads_amd import host
+    from tests import common
+    from tests.test_hip_parity import _gen
+    its, tlr = 20, 2.0
+    path = _gen("blk16x4000")
+    statefile = "/tmp/lorads_shard_state_%d.npz" % os.getpid()
+    refstate = "/tmp/lorads_shard_state_%d.bin" % os.getpid()
+    s = host.Session.open(path)
+    s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+    s.prepare(1, 0)
+    s.attach_hip()
+    try:
+        s.alm()
+        s.alm_to_admm()
+        res = s.results()
+        rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
+        be = s.be
+        nb = s.nblk
+        UV = [(be.get_mat(host.MAT_U, k), be.get_mat(host.MAT_V, k)) for k in range(nb)]
+        lam = be.get_vec(host.VEC_LAMBDA)
+        np.savez(statefile, rho=rho, lam=lam, **{"U%d" % k: UV[k][0] for k in range(nb)}, **{"V%d" % k: UV[k][1] for k in range(nb)})
+        with open(refstate, "wb") as f:
+            for U, V in UV:
+                f.write(np.asfortranarray(U).tobytes(order="F"))
+                f.write(np.asfortranarray(V).tobytes(order="F"))
+            f.write(lam.tobytes())
+        be.init_constr(host.PAIR_UV)
+        be.cal_obj(host.PAIR_UV)
+        e0 = be.update_dimacs(host.PAIR_UV)
+        e1, cg1, p1, d1 = bench.admm_steps(be, host, rho, e0, its, s)
+        U_one = [be.get_mat(host.MAT_U, k) for k in range(nb)]
+        ranks = [s.block_shape(k)[1] for k in range(nb)]
+    finally:
+        s.close()
+    ref = None
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(drv):
+        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", LORADS_REF_UV_RANKS=",".join(str(r) for r in ranks))
+        r = subprocess.run([drv, path, "admmbench", "-", "--timesLogRank", repr(tlr), "--rho", repr(rho), "--uv", refstate, "--nADMM", str(its)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("@@REF_ADMM_BENCH")]
+        assert r.returncode == 0 and line, r.stderr[-800:]
+        ref = dict(x.split("=") for x in line[0].split()[1:])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fullsize, args=(r, world, port, path, tlr, statefile, its, separable, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        out = dict(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        for f in (statefile, refstate):
+            if os.path.exists(f):
+                os.remove(f)
+    a = out[0]
+    assert sum(out[r]["nblk_local"] for r in range(world)) == nb
+    assert all(out[r]["separable"] == separable for r in range(world))
+    for r in range(1, world):   # every rank holds the same summed scalars
+        for k in ("pObj", "dObj", "err1", "err0"):
+            assert a[k] == out[r][k], (r, k, a[k], out[r][k])
+    cg = sum(out[r]["cg"] for r in range(world))
+    print("blk16x4000 world", world, "separable" if separable else "m-vector", "cg", cg, int(cg1), "pObj", a["pObj"], p1, "dObj", a["dObj"], d1,
+          "err1", a["err1"], e1, "reference", ref)
+    assert cg == int(cg1), (cg, cg1)
+    assert a["pObj"] == pytest.approx(p1, rel=1e-11) and a["dObj"] == pytest.approx(d1, rel=1e-11)
+    assert a["err1"] == pytest.approx(e1, rel=1e-6, abs=1e-14)
+    for r in range(world):
+        for name, U in out[r]["U"].items():
+            k = int(name[1:])
+            assert np.allclose(U, U_one[k], rtol=0, atol=1e-9 * np.abs(U_one[k]).max()), (r, k)
+    if ref:
+        assert cg == int(ref["cg_iters"])
+        assert a["pObj"] == pytest.approx(float(ref["pObj"]), rel=1e-10) and a["dObj"] == pytest.approx(float(ref["dObj"]), rel=1e-10)
