@@ -75,7 +75,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MAXPART = 4096; // capacity of one partial-sum slot
+constexpr int MINPART = 4096; // least capacity of one partial-sum slot; a context sizes its slots to its largest cone (lorads_hip_ctx::maxpart)
 constexpr int NSLOT = 20; // (18, 19: start-of-solve and restart residual partials of the ADMM sweep, see solve_front)
 
 thread_local std::string g_err;
@@ -492,7 +492,9 @@ struct lorads_hip_ctx {
     int ar_fast_all = -1;     // every rank holds one cone that can send its objective partials through the all-reduce (-1: not yet agreed)
     bool opt_ar_fast = true;
     double *b = nullptr, *lambda = nullptr, *csum = nullptr, *q12 = nullptr; // csum: m+2, q12: 2m+2
-    double *part = nullptr;   // NSLOT x MAXPART partial sums
+    double *part = nullptr;   // NSLOT x maxpart partial sums
+    int maxpart = MINPART;    // capacity of one slot: one partial per workgroup of the widest row kernel of the largest cone (4 rows per
+                              // workgroup at 64 lanes per row), so no cone dimension and no rank is refused for want of partial-sum room
     int ls_np = 0;            // line-search partials (slots 10..16) currently valid for q1, q2: how many per sum
     char *ctrl = nullptr, *h_ctrl = nullptr; // [64 scalars | CG states] device + pinned mirror: ONE readback copy
     char *h_ctrl_dev = nullptr;              // device address of the pinned mirror (k_publish writes it directly)
@@ -603,7 +605,7 @@ inline bool use_v2(int r) { return (r % 2) == 0 && r <= 128; }
 inline int lg_for(int r) { return use_v2(r) ? 8 : (r <= 64 ? 8 : (r <= 256 ? 32 : 64)); }
 const Guard NOGUARD{nullptr, nullptr};
 
-double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * MAXPART; }
+double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * c->maxpart; }
 // sharded cones that share constraints: constrValSum, q1, q2 are summed over the ranks as m-vectors.  Separable shards
 // (lorads_hip_set_separable) hold their own constraints: only scalars are summed (c->ar && c->sep).
 inline bool shard_vec(const lorads_hip_ctx *c) { return c->ar && !c->sep; }
@@ -627,6 +629,17 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     lorads_hip_ctx *c = new lorads_hip_ctx();
     c->m = prob->m; c->nb = prob->nblocks; c->L = std::max(prob->lbfgs_len, 1); c->b_nrm1 = prob->b_nrm1;
     HC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    { // partial-sum slots: room for every row kernel's grid at any rank (the merged cone of all blocks included)
+        size_t rows_max = 0, rows_all = 0;
+        for (int k = 0; k < c->nb; ++k) {
+            const size_t nk = (size_t)std::max(prob->blocks[k].n, 0);
+            rows_max = std::max(rows_max, nk);
+            rows_all += (nk + 31) & ~(size_t)31;
+        }
+        const size_t need = (std::max(rows_max, rows_all) + 3) / 4 + 1;
+        if (need > ((size_t)1 << 27)) { delete c; return fail_msg("cone dimension beyond 2^29 rows"); }
+        c->maxpart = (int)std::max<size_t>((size_t)MINPART, (need + 255) & ~(size_t)255);
+    }
     c->blk.resize(c->nb);
     for (int k = 0; k < c->nb; ++k)
         if (build_block(c, c->blk[k], prob->blocks[k])) { lorads_hip_destroy(c); return 1; }
@@ -637,8 +650,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     if (alloc_factors(c)) { lorads_hip_destroy(c); return 1; }
     std::vector<double> hb(prob->b, prob->b + c->m);
     if (upload(&c->b, hb) || dalloc(&c->lambda, (size_t)c->m) || dalloc(&c->lambda_alt, (size_t)c->m) || dalloc(&c->csum, (size_t)c->m + 2) ||
-        dalloc(&c->cstage, (size_t)c->m + 2 + MAXPART) || dalloc(&c->gram, 128) ||
-        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * MAXPART) ||
+        dalloc(&c->cstage, (size_t)c->m + 2 + MINPART) || dalloc(&c->gram, 128) ||
+        dalloc(&c->q12, (size_t)2 * c->m + 2) || dalloc(&c->part, (size_t)NSLOT * c->maxpart) ||
         dalloc(&c->ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)) ||
         dalloc(&c->ring_ab, (size_t)2 * c->L) || dalloc(&c->par, 8) || dalloc(&c->seq_dev, 2)) {
         lorads_hip_destroy(c);
@@ -855,7 +868,7 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
             V.v[1 + t] = c->ring[node].y;
             V.v[1 + nn + t] = c->ring[node].s;
         }
-        const int g = std::max(1, std::min(std::min(gv, 256), 5 * MAXPART / npair)); // (partials: slots 3..7, consumed at once)
+        const int g = std::max(1, std::min(std::min(gv, 256), 5 * c->maxpart / npair)); // (partials: slots 3..7, consumed at once)
         double *part = part_slot(c, 3);
 #define GRAM_NV(NV_) case NV_: LAUNCH((k_gram<NV_>), g, n, V, part); break
         switch (nv) { GRAM_NV(3); GRAM_NV(5); GRAM_NV(7); GRAM_NV(9); default: LAUNCH((k_gram<11>), g, n, V, part); break; }
@@ -911,7 +924,7 @@ static int enqueue_q12p12(lorads_hip_ctx *c, int *defer_p12 = nullptr) {
         B.t_uv_valid = false;
         c->ls_np = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
         LAUNCH(k_cv_rd, c->ls_np, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.T, B.cv, B.row_idx, c->q12, c->q12 + m, c->b, c->csum,
-               c->lambda, part_slot(c, 10));
+               c->lambda, part_slot(c, 10), c->maxpart);
         const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
         SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4),
                                   part_slot(c, 6)));
@@ -956,10 +969,10 @@ static void quartic_coeffs(double rho, double p1, double p2, const double s[5], 
 static void launch_linesearch(lorads_hip_ctx *c, double rho, int np_obj) {
     if (c->ls_np == 0) { // q1, q2 came from the general path: stream the m-vectors once, many workgroups
         c->ls_np = std::min(grid1d((size_t)c->m), 1024);
-        LAUNCH(k_linesearch_part, c->ls_np, c->m, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, part_slot(c, 10));
+        LAUNCH(k_linesearch_part, c->ls_np, c->m, c->b, c->csum, c->lambda, c->q12, c->q12 + c->m, part_slot(c, 10), c->maxpart);
     }
     LAUNCH(k_linesearch, 1, c->m, 1.0 / rho, part_slot(c, 10), c->ls_np, c->q12, c->scal + 16,
-           np_obj ? part_slot(c, 4) : (const double *)nullptr, np_obj ? part_slot(c, 6) : (const double *)nullptr, np_obj);
+           np_obj ? part_slot(c, 4) : (const double *)nullptr, np_obj ? part_slot(c, 6) : (const double *)nullptr, np_obj, c->maxpart);
 }
 int lorads_hip_alm_linesearch_coeffs(lorads_hip_ctx *c, double rho, double p1, double p2, double k[4]) {
     launch_linesearch(c, rho, 0);
@@ -1235,7 +1248,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
             return fail_msg("resize_rank: this cone's dense objective kernel supports rank <= 128");
         if (B.dense_a && nr[k] > 128 && B.ksplit_b == 0)
             return fail_msg("resize_rank: this cone's dense constraint kernel supports rank <= 128");
-        if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > MAXPART)
+        if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > c->maxpart)
             return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
     }
     double *old[4] = {c->R, c->U, c->V, c->G};
@@ -1321,7 +1334,7 @@ int lorads_hip_time_operator(lorads_hip_ctx *c, int32_t reps, double *ms) {
     const int prof0 = c->prof;
     c->prof = 0;
     HC(hipMemsetAsync(c->st, 0, sizeof(CGState) * 2, c->stream));
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * MAXPART, 1.0, c->part);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(TPB), 0, c->stream, (size_t)NSLOT * c->maxpart, 1.0, c->part);
     const bool tv = B.t_uv_valid;
     for (int it = -3; it < reps; ++it) {
         if (it == 0) HC(hipEventRecord(e0, c->stream));

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from lorads_amd import host
+from lorads_amd import host, instances
 from tests import common
 
 pytestmark = pytest.mark.gpu
@@ -1411,3 +1411,56 @@ def test_fullsize_admm_iterations_from_the_devices_own_state_vs_compiled_referen
         s.close()
         if os.path.exists(state):
             os.remove(state)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,r", [("matcomp50000", 91), ("matcomp50000", 135), ("maxcut140000", 40), ("rand140000", 24)])
+def test_large_cones_and_odd_ranks_are_not_refused(built, name, r):
+    """The reference has no limit on a cone's dimension or rank (data/lorads_solver.c:290-319).  The row kernels leave one partial
+    sum per workgroup, and their slots used to hold 4096: n = 50000 was refused at any odd rank above 64 (32 lanes per row: 8 rows per
+    workgroup) and n = 140000 at every rank.  The slots are now sized to the context's largest cone.  Function by function against
+    the oracle from the same factors (phase-1 gradient, direction, q1/q2, objective, DIMACS residual; three CG iterations of one
+    ADMM sweep), at n = 50000 with r = 91 and r = 135 (rank growth from 60) and at n = 140000."""
+    if name == "maxcut140000":
+        instances.NAMED.setdefault(name, lambda: instances.maxcut(140000, 6 * 140000, 140000))
+    if name == "rand140000":
+        instances.NAMED.setdefault(name, lambda: instances.randsparse(140000, 35000, 140001, c_edges=6 * 140000))
+    path = _gen(name)
+    tlr = 5.5 if name == "matcomp50000" else (r - 0.5) / np.log(140000)
+    hs, os_ = _pair(path, timesLogRank=float(tlr))
+    try:
+        n, r0 = hs.block_shape(0)
+        if r0 != r:
+            for s in (hs, os_):
+                s.be.resize_rank([r])
+        assert hs.block_shape(0) == (n, r) and os_.block_shape(0) == (n, r)
+        rng = np.random.default_rng(r)
+        R = rng.standard_normal((n, r)) / np.sqrt(n)
+        lam = 0.1 * rng.standard_normal(hs.m)
+        rho = 0.7
+        vals = []
+        for s in (hs, os_):
+            be = s.be
+            be.set_mat(host.MAT_R, 0, R)
+            be.set_vec(host.VEC_LAMBDA, lam)
+            be.init_constr(host.PAIR_RR)
+            lag = be.alm_cal_grad(rho)
+            G = be.get_mat(host.MAT_GRAD, 0)
+            be.lbfgs_direction(0)
+            p1, p2 = be.alm_q12p12()
+            q1, q2 = be.get_vec(host.VEC_Q1), be.get_vec(host.VEC_Q2)
+            po = be.cal_obj(host.PAIR_RR)
+            e1 = be.update_dimacs(host.PAIR_RR)
+            be.alm_to_admm()
+            be.init_constr(host.PAIR_UV)
+            it = be.admm_update_var(1.5, 1e-14, 3)       # (three CG iterations per solve: the limit, not the tolerance, stops them)
+            vals.append((np.array([lag, p1, p2, po, e1]), G, q1, q2, be.get_mat(host.MAT_U, 0), be.get_mat(host.MAT_V, 0), it))
+        a, b = vals
+        assert np.allclose(a[0], b[0], rtol=1e-9), (a[0], b[0])
+        assert np.allclose(a[1], b[1], rtol=0, atol=1e-10 * np.abs(b[1]).max())
+        assert np.allclose(a[2], b[2], rtol=0, atol=1e-10 * np.abs(b[2]).max()) and np.allclose(a[3], b[3], rtol=0, atol=1e-10 * np.abs(b[3]).max())
+        assert a[6] == b[6] == 6, (a[6], b[6])
+        assert np.allclose(a[4], b[4], rtol=0, atol=1e-8 * np.abs(b[4]).max()) and np.allclose(a[5], b[5], rtol=0, atol=1e-8 * np.abs(b[5]).max())
+    finally:
+        hs.close()
+        os_.close()
