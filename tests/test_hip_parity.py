@@ -1464,3 +1464,33 @@ def test_large_cones_and_odd_ranks_are_not_refused(built, name, r):
     finally:
         hs.close()
         os_.close()
+
+
+def _run_admm_steps(path, env, steps, **kw):
+    """phase 1 (the solver's own) + `steps` ADMM iterations under the environment `env`; returns (log, U, V, lambda)"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = common.hip_session(path, phase1Tol=1e-2, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        s.alm()
+        s.alm_to_admm()
+        s.be.init_constr(host.PAIR_UV)
+        res0 = s.results()
+        rho = min(res0["admm_rho"] if res0["admm_rho"] > 0 else res0["alm_rho"], 5000.0)
+        log = []
+        e = s.be.update_dimacs(host.PAIR_UV)
+        for it in range(steps):
+            c, p, d, e = s.be.admm_step(rho, min(1e-2 * e, 1e-8), 800)
+            s.be.update_dual_var(rho)
+            log.append((c, p, d, e))
+        return (log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)], [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)],
+                s.be.get_vec(host.VEC_LAMBDA), [s.hip_operator_kind(k) for k in range(s.nblk)])
+    finally:
+        s.close()
