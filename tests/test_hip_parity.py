@@ -1494,3 +1494,29 @@ def _run_admm_steps(path, env, steps, **kw):
                 s.be.get_vec(host.VEC_LAMBDA), [s.hip_operator_kind(k) for k in range(s.nblk)])
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name", ["rand120", "maxcut100", "blk4x60", "theta30"])
+def test_gram_form_direction_on_one_gpu_replays_the_reference_trace(built, monkeypatch, name):
+    """LORADS_LBFGS_GRAM=2: the L-BFGS direction of a single GPU in Gram form (one pass forms the 15 products of {Grad, y_t, s_t}, one
+    thread runs the two-loop recursion on coefficients, one pass forms D: two passes over the vectors instead of five) -- the sharded
+    path's form, on one rank.  Against the reference's golden trace, and through a whole solve against the default form."""
+    monkeypatch.setenv("LORADS_LBFGS_GRAM", "2")
+    g = common.golden_trace(name)
+    s = common.hip_session(common.instance_path(name))
+    try:
+        log = common.replay_trace(s, g, rtol=1e-9, resync=True)
+        w = common.trace_worst(log)
+        print(name, "Gram-form direction, worst rel-to-scale errors", w)
+        assert w["phase1"] <= 1e-9, w
+    finally:
+        s.close()
+    res = []
+    for gram in ("2", "1"):
+        monkeypatch.setenv("LORADS_LBFGS_GRAM", gram)
+        with common.hip_session(common.instance_path(name), phase1Tol=1e-3) as s2:
+            s2.solve()
+            res.append(s2.results())
+    a, b = res
+    assert a["pObj"] == pytest.approx(b["pObj"], rel=1e-5) and a["dObj"] == pytest.approx(b["dObj"], rel=1e-5)
+    assert abs(a["alm_inner"] - b["alm_inner"]) <= max(5, 0.1 * b["alm_inner"]), (a["alm_inner"], b["alm_inner"])
