@@ -407,6 +407,9 @@ struct Block {
     double *Adense = nullptr; // [nd][npad * npad]
     double *Sfull = nullptr;  // npad * npad scratch: [C +] sum_j mu_j A_j
     double *d_mu = nullptr;   // [nd] the weights of the current combination
+    double *Wj = nullptr;     // [nd][n * r]: W_j = A_j Y of the dense constraint matrices for the factor Y = wj_for (dense_cache_fill) ...
+    double *Wc = nullptr;     // ... and C Y of a dense objective beside them
+    const double *wj_for = nullptr; // the factor array the kept products belong to (null: none)
     bool t_uv_valid = false;  // B.T currently holds the pair dots of (U,V) (symmetric in the pair)
     double *T2 = nullptr;     // second pair-dot buffer (evaluation on R) so that T(U,V) survives it
     bool diag_only = false;   // every A_i is a single diagonal entry (Max-Cut)
@@ -528,6 +531,7 @@ struct lorads_hip_ctx {
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
     bool opt_dense_rem = true; // dense GEMM: 1..4 columns beyond the full tiles on plain FMAs instead of a tile of their own (LORADS_DENSE_REM=0)
+    bool opt_dense_cache = true; // dense constraint matrices: A_j V kept for the length of a CG solve (LORADS_DENSE_CACHE=0: nd + 1 GEMMs per application)
     bool opt_dense_b = true;  // dense objective: C read as the MFMA B operand (k_dense_cx_b; LORADS_DENSE_B=0: k_dense_cx)
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
     bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
@@ -684,6 +688,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_eval_diag = !(getenv("LORADS_EVAL_DIAG") && getenv("LORADS_EVAL_DIAG")[0] == '0');
     c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
     c->opt_dense_b = !(getenv("LORADS_DENSE_B") && getenv("LORADS_DENSE_B")[0] == '0');
+    c->opt_dense_cache = !(getenv("LORADS_DENSE_CACHE") && getenv("LORADS_DENSE_CACHE")[0] == '0');
     c->opt_fuse_eval = !(getenv("LORADS_FUSE_EVAL") && getenv("LORADS_FUSE_EVAL")[0] == '0');
     c->opt_dense_rem = !(getenv("LORADS_DENSE_REM") && getenv("LORADS_DENSE_REM")[0] == '0');
     c->opt_exact_refresh = getenv("LORADS_EXACT_REFRESH") && getenv("LORADS_EXACT_REFRESH")[0] == '1';
@@ -1156,7 +1161,7 @@ int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
 
 static void invalidate_t(lorads_hip_ctx *c) {
     c->merged.t_uv_valid = false;
-    for (auto &B : c->blk) B.t_uv_valid = false;
+    for (auto &B : c->blk) { B.t_uv_valid = false; B.wj_for = nullptr; }
 }
 
 int lorads_hip_alm_to_admm(lorads_hip_ctx *c) {
@@ -1176,6 +1181,7 @@ int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
 
 int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
     c->ls_np = 0;
+    for (auto &B0 : c->blk) B0.wj_for = nullptr; // (kept products C Y of a dense objective are those of the old C)
     std::vector<Block *> all;
     for (auto &B0 : c->blk) all.push_back(&B0);
     if (c->merged_ok) all.push_back(&c->merged); // the merged cone carries its own copy of the objective
@@ -1198,6 +1204,7 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
     if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
     Block &B = c->blk[k];
     B.t_uv_valid = false;
+    B.wj_for = nullptr;
     c->merged.t_uv_valid = false; // (its pair values of (U, V) cover this cone too)
     std::vector<double> rm((size_t)B.n * B.r);
     for (int j = 0; j < B.r; ++j)

@@ -1520,3 +1520,27 @@ def test_gram_form_direction_on_one_gpu_replays_the_reference_trace(built, monke
     a, b = res
     assert a["pObj"] == pytest.approx(b["pObj"], rel=1e-5) and a["dObj"] == pytest.approx(b["dObj"], rel=1e-5)
     assert abs(a["alm_inner"] - b["alm_inner"]) <= max(5, 0.1 * b["alm_inner"]), (a["alm_inner"], b["alm_inner"])
+
+
+@pytest.mark.parametrize("name,tlr", [("densea40", None), ("densea300", 2.0), ("denseac200", 3.0)])
+def test_dense_constraint_products_kept_for_a_solve_equal_the_per_application_gemms(built, name, tlr):
+    """Cones with dense constraint matrices: W_j = A_j V is formed once per CG solve (V is fixed for its length) and every operator
+    application takes <A_j, sym(x V^T)> = <x, W_j> and (sum_j mu_j A_j) V = sum_j mu_j W_j from it -- nd GEMMs per solve instead of
+    nd + 1 per application.  LORADS_DENSE_CACHE=0: the per-application form.  Same CG iteration counts, iterates equal to rounding;
+    and the kept form is the faster one."""
+    import time
+    path = common.instance_path(name) if name == "densea40" else _gen(name)
+    kw = dict(timesLogRank=tlr) if tlr else {}
+    out = []
+    for cache in ("1", "0"):
+        t0 = time.perf_counter()
+        r = _run_admm_steps(path, {"LORADS_DENSE_CACHE": cache}, 12, **kw)
+        out.append((r, time.perf_counter() - t0))
+    (a, ta), (b, tb) = out
+    assert all("dense A_i" in k for k in a[4]), a[4]
+    print(name, "12 ADMM iterations + phase 1: kept products %.3f s, per-application GEMMs %.3f s; CG iterations" % (ta, tb), [x[0] for x in a[0]][:6])
+    for x, y in zip(a[0], b[0]):
+        assert abs(x[0] - y[0]) <= max(2, 0.02 * y[0]), (x, y)
+        assert x[1] == pytest.approx(y[1], rel=1e-8, abs=1e-10) and x[2] == pytest.approx(y[2], rel=1e-8, abs=1e-10)
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert np.allclose(x, y, rtol=0, atol=1e-7 * np.abs(y).max())
