@@ -572,6 +572,9 @@ struct lorads_hip_ctx {
     bool sep = false; // lorads_hip_set_separable: this context holds one rank's own constraints; only scalars cross the ranks
     double *sepbuf = nullptr; // 32: scalars on their way through the all-reduce in that mode
     SepExtra sep_extra{};     // scalars the next evaluation's all-reduce also carries (set by the caller, taken by enqueue_eval)
+    bool sep_pending = false; // the reduced scalars of a separable evaluation wait for the hand-over kernel to commit them (k_publish_sep)
+    int sep_with_obj = 0;
+    SepExtra sep_ex{};
     double *gram = nullptr;   // 128: [0..66) products V_a.V_b of the Gram-form L-BFGS direction, [80..91) the coefficients of D
     bool opt_gram = true;     // LORADS_LBFGS_GRAM=0: sharded direction by the sequential recursion, one collective per dot
     bool opt_gram_single = false; // LORADS_LBFGS_GRAM=2: the Gram-form direction on a single GPU as well
@@ -1077,6 +1080,7 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         c->sep_extra.p[0] = c->scal + 8;
         c->sep_extra.p[1] = c->scal + 9;
         if (enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) return 1;
+        flush_pending(c); // (the reduced y.s must be committed before it is read)
         hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(1), 0, c->stream, (int)SOP_BETA, c->scal + 9, c->ring_ab + 2 * hd, c->ring_ab + 2 * hd + 1,
                            c->scal + 10);
     } else if (lorads_hip_set_y_as_neg_grad(c) || lorads_hip_alm_update_var(c, tau) || enqueue_alm_grad(c, rho) ||
