@@ -51,8 +51,12 @@ elif "k_op_entry_bip" in ks:
 elif "k_op_entry" in ks:
     op = ks["k_op_entry"]["read_bytes_median"] + ks["k_op_entry"]["write_bytes_mean"]
     out["cg_operator_application"] = {"kernels": ["k_op_entry"], "traffic_bytes": op}
+elif "k_front_cw" in ks and "k_wsum" in ks and "k_spmm_ell" in ks:
+    # constraint-wise operator AS THE DEFAULT RUN APPLIES IT (iteration 0 behind the one-kernel front): k_wsum + k_spmm_ell
+    op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_wsum", "k_spmm_ell"))
+    out["cg_operator_application"] = {"kernels": ["k_wsum", "k_spmm_ell"], "traffic_bytes": op}
 elif "k_cw" in ks and "k_spmm_ell" in ks:
-    # constraint-wise operator: k_cw (constraint values from the factors) + k_spmm_ell (fixed-width slot list)
+    # constraint-wise operator, general form: k_cw (constraint values from the factors) + k_spmm_ell (fixed-width slot list)
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_cw", "k_spmm_ell"))
     out["cg_operator_application"] = {"kernels": ["k_cw", "k_spmm_ell"], "traffic_bytes": op}
     if "k_spmm2" in ks:  # front of a solve (right-hand side + initial residual in one pass)

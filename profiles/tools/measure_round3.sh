@@ -1,17 +1,19 @@
 #!/bin/bash
-# Round-2 measurement, part $1 = bench | prof | pmc  (each fits one gpurun call); outputs under gpurun_out/r02m/
+# Round-3 measurement, part $1 = bench | prof | pmc  (each fits one gpurun call); outputs under gpurun_out/r03m/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02m; mkdir -p $O
+O=gpurun_out/r03m; mkdir -p $O
 B="--no-cpu --no-extra --windows 1 --roofline-samples 0"
 case "$1" in
 bench)
   python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$?"
   python bench.py --workload matcomp50000 --steps 40 --warmup 4 --cpu-budget 30 > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 rc=$?"
   python bench.py --workload blk16x4000 --times-log-rank 2.0 --steps 100 --warmup 5 > $O/bench_cfg4_1gpu.json 2> $O/bench_cfg4_1gpu.err; echo "cfg4 rc=$?"
+  python bench.py --workload maxcut800 --times-log-rank 2.0 --steps 200 --warmup 10 --no-extra > $O/bench_cfg2_maxcut800.json 2> $O/bench_cfg2.err; echo "cfg2 rc=$?"
   LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus2_weak_gloo_one_card.json 2> $O/rehearsal_gpus2.err; echo "gpus2 rc=$?"
   LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 4 --scaling strong --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus4_strong_gloo_one_card.json 2> $O/rehearsal_gpus4.err; echo "gpus4 rc=$?"
-  python profiles/tools/ubench.py 200 1,2,30,31,32,8,10 > $O/ubench.txt 2> $O/ubench.err
-  python profiles/tools/stamp.py r02 $O
+  python profiles/tools/ubench.py 200 1,2,30,31,32,8,10,23,24 > $O/ubench.txt 2> $O/ubench.err
+  python profiles/tools/size_sweep.py 200 > $O/size_sweep.txt 2> $O/size_sweep.err
+  python profiles/tools/stamp.py r03 $O
   ;;
 prof)
   for w in rand20000 maxcut20000 matcomp50000 blk16x4000; do
@@ -26,7 +28,7 @@ prof)
   LORADS_FRONT_CW=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_general -o p -- python3 bench.py $B --steps 50 --warmup 5 > $O/kt_general.log 2>&1
   T=$(ls $O/kt_general/*kernel_trace.csv | head -1); python profiles/trace_summary.py $T > $O/rand20000_general_form_admm_part_summary.txt; rm -f $T
   cp $O/kt_general/p_kernel_stats.csv $O/rand20000_general_form_kernel_stats.csv
-  python profiles/tools/stamp.py r02 $O
+  python profiles/tools/stamp.py r03 $O
   ;;
 pmc)
   for w in rand20000 maxcut20000; do
@@ -60,7 +62,7 @@ if f:
 import os
 for x in f: os.remove(x)
 PY
-  python profiles/tools/stamp.py r02 $O
+  python profiles/tools/stamp.py r03 $O
   ;;
 esac
 echo ALLDONE $1

@@ -1544,3 +1544,26 @@ def test_dense_constraint_products_kept_for_a_solve_equal_the_per_application_ge
         assert x[1] == pytest.approx(y[1], rel=1e-8, abs=1e-10) and x[2] == pytest.approx(y[2], rel=1e-8, abs=1e-10)
     for x, y in zip(a[1] + a[2], b[1] + b[2]):
         assert np.allclose(x, y, rtol=0, atol=1e-7 * np.abs(y).max())
+
+
+@pytest.mark.parametrize("name,tlr,knob", [("maxcut800", None, "LORADS_FRONT_DIAG"), ("maxcut800", None, "LORADS_EVAL_DIAG"),
+                                           ("maxcut800", None, "LORADS_FUSE_DIR"), ("maxcut800", None, "LORADS_TILE_UPDATE"),
+                                           ("rand4000", 4.0, "LORADS_FOLD_AVG"), ("rand4000", 4.0, "LORADS_FUSE_EVAL"),
+                                           ("rand4000", 4.0, "LORADS_CW_QUAD")])
+def test_fused_paths_equal_the_step_by_step_forms(built, name, tlr, knob):
+    """Every re-arrangement of the launch chain keeps a switch that restores the form it replaces.  Those that no
+    other test sets side by side: the Max-Cut front's on-the-fly diagonal coefficients, the one-kernel evaluation of Max-Cut cones,
+    the direction update inside k_op_diag, k_cg_update on the operator's row tiles; the average folded into the last update, the
+    evaluation in one launch and the four-lane k_cw of cones on the k_cw path.  Each switched off against the default over 25 ADMM
+    iterations from the solver's own phase 1: same CG iteration counts (+-1 where a test sits on its threshold), objectives to
+    1e-9, factors to 1e-8 of scale (same sums, other groupings)."""
+    path = _gen(name) if name == "rand4000" else common.instance_path(name)
+    kw = dict(timesLogRank=tlr) if tlr else {}
+    a = _run_admm_steps(path, {}, 25, **kw)
+    b = _run_admm_steps(path, {knob: "0"}, 25, **kw)
+    for it, (x, y) in enumerate(zip(a[0], b[0])):
+        assert abs(x[0] - y[0]) <= 1, (it, x, y)
+        assert x[1] == pytest.approx(y[1], rel=1e-9, abs=1e-11) and x[2] == pytest.approx(y[2], rel=1e-9, abs=1e-11), (it, x, y)
+    assert np.allclose(a[3], b[3], rtol=0, atol=1e-8 * max(np.abs(b[3]).max(), 1e-300))
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert np.allclose(x, y, rtol=0, atol=1e-8 * np.abs(y).max())
