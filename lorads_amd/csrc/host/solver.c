@@ -138,10 +138,17 @@ void lrd_solver_clear(lrd_solver *s) {
 /* "time is up?" -- with sharded cones every rank must take the same branch, or the ones that stay enter the next
  * collective alone and wait for ever: the clocks are the only control input that is not rank-uniform, so the verdicts
  * are summed over the ranks (anybody's time-out ends it for all).  Called at the same control points on every rank. */
+/* A table slot that failed on ONE rank (be_fail) travels with the same sum: every rank then leaves at this control point with
+ * LRD_RET_NUM_ERR instead of the healthy ones entering the next device collective alone.  (A rank whose slot fails inside a sweep
+ * that contains a collective cannot be waited for by its peers: their hand-over reports it after LORADS_HANDOVER_TIMEOUT_S, default
+ * 300 s, and the solve ends with a non-zero return code -- lorads_hip.h, "result hand-over".) */
 static int time_is_up(lrd_solver *s, double t_start, double limit) {
-    double v = (lrd_time() - t_start >= limit) ? 1.0 : 0.0;
-    if (s->allreduce) BE(s->allreduce(s->allreduce_user, &v, 1, 0));
-    return v > 0.0;
+    double v[2] = {(lrd_time() - t_start >= limit) ? 1.0 : 0.0, s->be_fail ? 1.0 : 0.0};
+    if (s->allreduce) {
+        if (s->allreduce(s->allreduce_user, v, 2, 0) != 0) s->be_fail = 1;
+        if (v[1] > 0.0) s->be_fail = 1; /* somebody's backend failed: everybody stops */
+    }
+    return (s->allreduce && s->be_fail) ? 2 : (v[0] > 0.0 ? 1 : 0); /* 2: a backend failure somewhere, 1: time */
 }
 
 static double inf_from_l1(const lrd_solver *s, double l1) {
@@ -392,7 +399,7 @@ restart:
             goto print_and_exit;
         }
         alm_log(par, st, lrd_time() - t_ori);
-        if (time_is_up(s, t_start, par->timeSecLimit)) goto print_and_exit;
+        { const int tu = time_is_up(s, t_start, par->timeSecLimit); if (tu == 2) { ret = LRD_RET_NUM_ERR; goto end_alm; } if (tu) goto print_and_exit; }
         if (rank_flag >= rank_thres && !is_rank_max && (!reopt || s->prob->nsdp_global <= 10)) {
             rank_flag = 0;
             if (k - last_outer_start >= 2) {
@@ -532,7 +539,7 @@ int lrd_admm_optimize(lrd_params *par, lrd_solver *s, int reopt, int iter_ceilin
             refresh_dimacs(s, LRD_PAIR_UV);
             admm_pull_state(s, 1);
             admm_log(par, d, lrd_time() - t_ori);
-            if (time_is_up(s, t_start, par->timeSecLimit)) return LRD_RET_TIME_OUT;
+            { const int tu = time_is_up(s, t_start, par->timeSecLimit); if (tu == 2) return LRD_RET_NUM_ERR; if (tu) return LRD_RET_TIME_OUT; }
         }
         if (d->primal_dual_gap <= par->phase2Tol * 1e-3 && d->l_1_primal_infeasibility <= par->phase2Tol * 1e-3) {
             if (par->verbose) printf("Early Stop When DIMACS Errors Are Well-Satisfied");
@@ -623,7 +630,7 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
     lrd_alm_optimize(par, s, 0, 0, par->ALMRhoFactor, t0);
     s->t_alm = lrd_time() - ta;
     if (s->be_fail) return LRD_RET_NUM_ERR; /* a table slot failed: nothing below would be computed from real numbers */
-    if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
+    { const int tu = time_is_up(s, t0, par->timeSecLimit); if (tu == 2) return LRD_RET_NUM_ERR; if (tu) { s->status = LRD_TIME_LIMIT; return 0; } }
     lrd_alm_to_admm(par, s);
     ta = lrd_time();
     if (lrd_admm_optimize(par, s, 0, par->maxADMMIter, t0) == LRD_RET_BAD_ITER) bad = 1;
@@ -641,7 +648,7 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
             lrd_reopt(par, s, 5.0, 3, admm_reopt_min_iter, t0, &bad, 1);
             cnt += 1;
             if (s->be_fail) return LRD_RET_NUM_ERR;
-            if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
+            { const int tu = time_is_up(s, t0, par->timeSecLimit); if (tu == 2) return LRD_RET_NUM_ERR; if (tu) { s->status = LRD_TIME_LIMIT; return 0; } }
         }
     }
     const int have_dual = lrd_dual_infeasibility(s) == 0; /* main.c:400-413, evaluated at every reoptLevel */
@@ -666,7 +673,7 @@ int lrd_solve(lrd_params *par, lrd_solver *s) {
                 printf("reopt %d:Dual infeasibility: l_1 = %f, l_inf = %f, l_2 = %f\n", dual_cnt, d->l_1_dual_infeasibility,
                        d->l_inf_dual_infeasibility, d->l_2_dual_infeasibility);
             dual_cnt += 1;
-            if (time_is_up(s, t0, par->timeSecLimit)) { s->status = LRD_TIME_LIMIT; return 0; }
+            { const int tu = time_is_up(s, t0, par->timeSecLimit); if (tu == 2) return LRD_RET_NUM_ERR; if (tu) { s->status = LRD_TIME_LIMIT; return 0; } }
         }
         if (d->l_1_dual_infeasibility <= 5 * par->phase2Tol && d->primal_dual_gap <= 5 * par->phase2Tol &&
             d->l_1_primal_infeasibility <= par->phase2Tol)
