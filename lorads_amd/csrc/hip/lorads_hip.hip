@@ -538,6 +538,7 @@ struct lorads_hip_ctx {
     bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
     bool opt_tile_update = true; // Max-Cut-type cones: k_cg_update on the row tiles of k_op_diag (LORADS_TILE_UPDATE=0: grid-stride over the flat vector)
     bool avg_folded = false;  // ... and has done so for the evaluation that is enqueued next
+    bool opt_front_lds = true; // k_front_cw parks the first four slot rows in LDS for its second visit (LORADS_FRONT_LDS=0: gathered again)
     bool opt_front_cw = true; // k_front_cw + k_wsum instead of k_sval + k_spmm2<FRONT> + iteration 0's k_cw (LORADS_FRONT_CW=0: the latter)
     bool pend_dual_virtual = false; // the pending dual update has already been USED (formed on the fly by k_front_cw) but not stored
     bool opt_exact_refresh = false, opt_split_front = false; // test knobs (read at creation): see constr_by_recurrence, fused_front
@@ -685,6 +686,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
+    c->opt_front_lds = !(getenv("LORADS_FRONT_LDS") && getenv("LORADS_FRONT_LDS")[0] == '0');
     if (getenv("LORADS_SPEC_WINDOW")) c->spec_window = std::max(1, std::min(8, atoi(getenv("LORADS_SPEC_WINDOW"))));
     c->opt_fold_avg = !(getenv("LORADS_FOLD_AVG") && getenv("LORADS_FOLD_AVG")[0] == '0');
     c->opt_tile_update = !(getenv("LORADS_TILE_UPDATE") && getenv("LORADS_TILE_UPDATE")[0] == '0');
