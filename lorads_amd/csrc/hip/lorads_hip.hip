@@ -578,7 +578,7 @@ struct lorads_hip_ctx {
     SepExtra sep_ex{};
     double *gram = nullptr;   // 128: [0..66) products V_a.V_b of the Gram-form L-BFGS direction, [80..91) the coefficients of D
     bool opt_gram = true;     // LORADS_LBFGS_GRAM=0: sharded direction by the sequential recursion, one collective per dot
-    bool opt_gram_single = false; // LORADS_LBFGS_GRAM=2: the Gram-form direction on a single GPU as well
+    bool opt_gram_single = true; // the Gram-form direction on a single GPU as well (LORADS_LBFGS_GRAM=0: the stage kernels of the recursion)
     // profiling
     int prof = 0, prof_every = 8;
     int prof_target = 0;      // what a profiling window times: 0 = CG operator applications, 1 = solve fronts (lorads_hip_profile_target)
@@ -679,7 +679,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
     c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
-    c->opt_gram_single = getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '2';
+    c->opt_gram_single = c->opt_gram;
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
@@ -833,8 +833,9 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     const size_t n = c->all_elem;
     const int gv = c->ar ? grid1d(n) : grid_lbfgs(n);
     double *D = c->U;
-    // (LORADS_LBFGS_GRAM=2: the Gram form on one GPU too -- two passes over the vectors instead of five, four launches instead of six;
-    // the dots are then combinations of the 15 products and round differently from the recursion's, so the default stays the recursion)
+    // (one GPU, default since round 3: the Gram form too -- two passes over the vectors instead of five, four launches instead of six;
+    // its dots are combinations of the 15 products and round differently from the recursion's (1e-16 of scale): whole solves keep the
+    // reference's iteration counts on every instance under test.  LORADS_LBFGS_GRAM=0: the recursion, stage by stage)
     if (!c->ar && !(c->opt_gram_single && c->L <= 5)) { // single rank: one kernel per stage of the recursion (5 + 1 launches for history 2)
         double *pp[2] = {part_slot(c, 3), part_slot(c, 5)};
         int cur = 0;

@@ -1498,21 +1498,22 @@ def _run_admm_steps(path, env, steps, **kw):
 
 @pytest.mark.parametrize("name", ["rand120", "maxcut100", "blk4x60", "theta30"])
 def test_gram_form_direction_on_one_gpu_replays_the_reference_trace(built, monkeypatch, name):
-    """LORADS_LBFGS_GRAM=2: the L-BFGS direction of a single GPU in Gram form (one pass forms the 15 products of {Grad, y_t, s_t}, one
-    thread runs the two-loop recursion on coefficients, one pass forms D: two passes over the vectors instead of five) -- the sharded
-    path's form, on one rank.  Against the reference's golden trace, and through a whole solve against the default form."""
-    monkeypatch.setenv("LORADS_LBFGS_GRAM", "2")
+    """The L-BFGS direction of a single GPU in Gram form (one pass forms the 15 products of {Grad, y_t, s_t}, one thread runs the
+    two-loop recursion on coefficients, one pass forms D: two passes over the vectors instead of five; the default since round 3) and
+    as the stage-by-stage recursion (LORADS_LBFGS_GRAM=0).  Both against the reference's golden trace, and through a whole solve
+    against each other."""
+    monkeypatch.setenv("LORADS_LBFGS_GRAM", "0")
     g = common.golden_trace(name)
     s = common.hip_session(common.instance_path(name))
     try:
         log = common.replay_trace(s, g, rtol=1e-9, resync=True)
         w = common.trace_worst(log)
-        print(name, "Gram-form direction, worst rel-to-scale errors", w)
+        print(name, "stage-by-stage recursion, worst rel-to-scale errors", w)
         assert w["phase1"] <= 1e-9, w
     finally:
         s.close()
     res = []
-    for gram in ("2", "1"):
+    for gram in ("1", "0"):
         monkeypatch.setenv("LORADS_LBFGS_GRAM", gram)
         with common.hip_session(common.instance_path(name), phase1Tol=1e-3) as s2:
             s2.solve()
