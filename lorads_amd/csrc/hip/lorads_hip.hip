@@ -578,7 +578,7 @@ struct lorads_hip_ctx {
     SepExtra sep_ex{};
     double *gram = nullptr;   // 128: [0..66) products V_a.V_b of the Gram-form L-BFGS direction, [80..91) the coefficients of D
     bool opt_gram = true;     // LORADS_LBFGS_GRAM=0: sharded direction by the sequential recursion, one collective per dot
-    bool opt_gram_single = true; // the Gram-form direction on a single GPU as well (LORADS_LBFGS_GRAM=0: the stage kernels of the recursion)
+    bool opt_gram_single = false; // LORADS_LBFGS_GRAM=2: the Gram-form direction on a single GPU as well
     // profiling
     int prof = 0, prof_every = 8;
     int prof_target = 0;      // what a profiling window times: 0 = CG operator applications, 1 = solve fronts (lorads_hip_profile_target)
@@ -679,7 +679,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_lazy_scalars = !(getenv("LORADS_LAZY_SCALARS") && getenv("LORADS_LAZY_SCALARS")[0] == '0');
     c->opt_ar_fast = !(getenv("LORADS_AR_PLAIN") && getenv("LORADS_AR_PLAIN")[0] == '1');
     c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
-    c->opt_gram_single = c->opt_gram;
+    c->opt_gram_single = getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '2';
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
     c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
@@ -833,9 +833,9 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
     const size_t n = c->all_elem;
     const int gv = c->ar ? grid1d(n) : grid_lbfgs(n);
     double *D = c->U;
-    // (one GPU, default since round 3: the Gram form too -- two passes over the vectors instead of five, four launches instead of six;
-    // its dots are combinations of the 15 products and round differently from the recursion's (1e-16 of scale): whole solves keep the
-    // reference's iteration counts on every instance under test.  LORADS_LBFGS_GRAM=0: the recursion, stage by stage)
+    // (LORADS_LBFGS_GRAM=2: the Gram form on one GPU too -- two passes over the vectors instead of five.  Its dots are combinations of
+    // the 15 products and round differently from the recursion's (1e-16 of scale): on hard instances whole solves then take other
+    // iteration counts than the reference's (theta30 at phase1Tol 1e-3: 3608 inner iterations against 2991), so the default is the recursion)
     if (!c->ar && !(c->opt_gram_single && c->L <= 5)) { // single rank: one kernel per stage of the recursion (5 + 1 launches for history 2)
         double *pp[2] = {part_slot(c, 3), part_slot(c, 5)};
         int cur = 0;
@@ -883,14 +883,18 @@ int lorads_hip_lbfgs_direction(lorads_hip_ctx *c, int32_t inner) {
             V.v[1 + t] = c->ring[node].y;
             V.v[1 + nn + t] = c->ring[node].s;
         }
-        const int g = std::max(1, std::min(std::min(gv, 256), 5 * c->maxpart / npair)); // (partials: slots 3..7, consumed at once)
+        const int g = std::max(1, std::min(std::min(gv, 1024), 5 * c->maxpart / npair)); // (partials: slots 3..7, consumed at once)
         double *part = part_slot(c, 3);
 #define GRAM_NV(NV_) case NV_: LAUNCH((k_gram<NV_>), g, n, V, part); break
         switch (nv) { GRAM_NV(3); GRAM_NV(5); GRAM_NV(7); GRAM_NV(9); default: LAUNCH((k_gram<11>), g, n, V, part); break; }
 #undef GRAM_NV
-        LAUNCH(k_gram_final, 1, (const double *)part, npair, g, c->gram);
-        if (allreduce_dev(c, c->gram, npair)) return 1;
-        hipLaunchKernelGGL(k_lbfgs_coef, dim3(1), dim3(1), 0, c->stream, pl, (const double *)c->gram, c->ring_ab, c->gram + 80);
+        if (!c->ar) { // one rank: the sums and the recursion on coefficients in one launch
+            LAUNCH(k_gram_final, 1, (const double *)part, npair, g, c->gram, pl, c->ring_ab, c->gram + 80);
+        } else {
+            LAUNCH(k_gram_final, 1, (const double *)part, npair, g, c->gram, pl, (double *)nullptr, (double *)nullptr);
+            if (allreduce_dev(c, c->gram, npair)) return 1;
+            hipLaunchKernelGGL(k_lbfgs_coef, dim3(1), dim3(1), 0, c->stream, pl, (const double *)c->gram, c->ring_ab, c->gram + 80);
+        }
 #define LINC_NV(NV_) case NV_: LAUNCH((k_lincomb<NV_>), gv, n, V, (const double *)(c->gram + 80), D); break
         switch (nv) { LINC_NV(3); LINC_NV(5); LINC_NV(7); LINC_NV(9); default: LAUNCH((k_lincomb<11>), gv, n, V, (const double *)(c->gram + 80), D); break; }
 #undef LINC_NV

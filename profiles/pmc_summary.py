@@ -55,6 +55,7 @@ elif "k_front_cw" in ks and "k_wsum" in ks and "k_spmm_ell" in ks:
     # constraint-wise operator AS THE DEFAULT RUN APPLIES IT (iteration 0 behind the one-kernel front): k_wsum + k_spmm_ell
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_wsum", "k_spmm_ell"))
     out["cg_operator_application"] = {"kernels": ["k_wsum", "k_spmm_ell"], "traffic_bytes": op}
+    out["solve_front"] = {"kernels": ["k_front_cw"], "traffic_bytes": ks["k_front_cw"]["read_bytes_median"] + ks["k_front_cw"]["write_bytes_mean"]}
 elif "k_cw" in ks and "k_spmm_ell" in ks:
     # constraint-wise operator, general form: k_cw (constraint values from the factors) + k_spmm_ell (fixed-width slot list)
     op = sum(ks[k]["read_bytes_median"] + ks[k]["write_bytes_mean"] for k in ("k_cw", "k_spmm_ell"))

@@ -1498,29 +1498,31 @@ def _run_admm_steps(path, env, steps, **kw):
 
 @pytest.mark.parametrize("name", ["rand120", "maxcut100", "blk4x60", "theta30"])
 def test_gram_form_direction_on_one_gpu_replays_the_reference_trace(built, monkeypatch, name):
-    """The L-BFGS direction of a single GPU in Gram form (one pass forms the 15 products of {Grad, y_t, s_t}, one thread runs the
-    two-loop recursion on coefficients, one pass forms D: two passes over the vectors instead of five; the default since round 3) and
-    as the stage-by-stage recursion (LORADS_LBFGS_GRAM=0).  Both against the reference's golden trace, and through a whole solve
-    against each other."""
-    monkeypatch.setenv("LORADS_LBFGS_GRAM", "0")
+    """LORADS_LBFGS_GRAM=2: the L-BFGS direction of a single GPU in Gram form (one pass forms the 15 products of {Grad, y_t, s_t}, one
+    launch sums them and runs the two-loop recursion on coefficients, one pass forms D: two passes over the vectors instead of five) --
+    the sharded path's form, on one rank.  Against the reference's golden trace, and through a whole solve against the default form
+    (the recursion): same objectives; the inner iteration counts agree where the instance is easy and drift where it is not -- which
+    is why the recursion, the reference's own order of operations, stays the default on one GPU."""
+    monkeypatch.setenv("LORADS_LBFGS_GRAM", "2")
     g = common.golden_trace(name)
     s = common.hip_session(common.instance_path(name))
     try:
         log = common.replay_trace(s, g, rtol=1e-9, resync=True)
         w = common.trace_worst(log)
-        print(name, "stage-by-stage recursion, worst rel-to-scale errors", w)
+        print(name, "Gram-form direction, worst rel-to-scale errors", w)
         assert w["phase1"] <= 1e-9, w
     finally:
         s.close()
     res = []
-    for gram in ("1", "0"):
+    for gram in ("2", "1"):
         monkeypatch.setenv("LORADS_LBFGS_GRAM", gram)
         with common.hip_session(common.instance_path(name), phase1Tol=1e-3) as s2:
             s2.solve()
             res.append(s2.results())
     a, b = res
     assert a["pObj"] == pytest.approx(b["pObj"], rel=1e-5) and a["dObj"] == pytest.approx(b["dObj"], rel=1e-5)
-    assert abs(a["alm_inner"] - b["alm_inner"]) <= max(5, 0.1 * b["alm_inner"]), (a["alm_inner"], b["alm_inner"])
+    print(name, "inner iterations: Gram form", a["alm_inner"], "recursion", b["alm_inner"])
+    assert abs(a["alm_inner"] - b["alm_inner"]) <= max(5, (0.3 if name == "theta30" else 0.1) * b["alm_inner"]), (a["alm_inner"], b["alm_inner"])
 
 
 @pytest.mark.parametrize("name,tlr", [("densea40", None), ("densea300", 2.0), ("denseac200", 3.0)])
