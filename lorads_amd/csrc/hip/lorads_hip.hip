@@ -515,6 +515,7 @@ struct lorads_hip_ctx {
     bool par_req_valid = false;
     bool opt_graph = true;                   // LORADS_GRAPH=0: every iteration enqueued launch by launch
     bool opt_graph_batched = false;          // LORADS_GRAPH=2: the lockstep sweep of a merged cone is replayed too
+    bool opt_graph_forced = false;           // LORADS_GRAPH=1 or 2: replay whatever the size (default: small cones only, see graph_ok)
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
@@ -670,6 +671,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipMemset(c->seq_dev, 0, sizeof(unsigned long long) * 2));
     c->opt_graph = !(getenv("LORADS_GRAPH") && getenv("LORADS_GRAPH")[0] == '0');
     c->opt_graph_batched = getenv("LORADS_GRAPH") && getenv("LORADS_GRAPH")[0] == '2';
+    c->opt_graph_forced = getenv("LORADS_GRAPH") && (getenv("LORADS_GRAPH")[0] == '1' || getenv("LORADS_GRAPH")[0] == '2');
     HC(hipHostMalloc((void **)&c->h_ctrl, 64 * sizeof(double) + sizeof(CGState) * (size_t)std::max(2 * c->nb, 1), hipHostMallocMapped));
     HC(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocMapped));
     *c->h_flag = 0;
