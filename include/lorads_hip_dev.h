@@ -49,6 +49,10 @@ int lorads_hip_block_image(lorads_hip_ctx *ctx, int32_t blk, int64_t image[16]);
 /* replay of captured launch chains (hipGraph; LORADS_GRAPH=0 switches it off): stats = {chains captured, chains replayed,
  * chains held now, 1 if the replay is enabled for this context} */
 int lorads_hip_graph_stats(lorads_hip_ctx *ctx, int64_t stats[4]);
+/* pattern work of the pre-solve on the device (lorads_amd/csrc/hip/presolve.inc; what AConePresolveData does with qsort and a hash
+ * table, data/lorads_sdp_conic.c:868-1076): stats = {sparsity patterns built by the device sorts, of these compared with the host
+ * construction (LORADS_PRESOLVE_CHECK=1; a difference fails lorads_hip_create)} */
+int lorads_hip_presolve_stats(lorads_hip_ctx *ctx, int64_t stats[2]);
 
 #ifdef __cplusplus
 }

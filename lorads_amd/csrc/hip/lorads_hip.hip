@@ -532,6 +532,10 @@ struct lorads_hip_ctx {
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
     bool opt_dense_rem = true; // dense GEMM: 1..4 columns beyond the full tiles on plain FMAs instead of a tile of their own (LORADS_DENSE_REM=0)
+    bool opt_dev_presolve = true;   // pattern work of the pre-solve on the device (presolve.inc; LORADS_DEV_PRESOLVE=0: host)
+    bool opt_presolve_check = false; // LORADS_PRESOLVE_CHECK=1: build every device pattern on the host too and compare
+    size_t dev_presolve_min = (size_t)1 << 15; // stored entries below which a pattern is built on the host (LORADS_DEV_PRESOLVE_MIN)
+    long long n_dev_patterns = 0, n_checked_patterns = 0;
     bool opt_dense_cache = true; // dense constraint matrices: A_j V kept for the length of a CG solve (LORADS_DENSE_CACHE=0: nd + 1 GEMMs per application)
     bool opt_dense_b = true;  // dense objective: C read as the MFMA B operand (k_dense_cx_b; LORADS_DENSE_B=0: k_dense_cx)
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
@@ -650,6 +654,9 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
         if (need > ((size_t)1 << 27)) { delete c; return fail_msg("cone dimension beyond 2^29 rows"); }
         c->maxpart = (int)std::max<size_t>((size_t)MINPART, (need + 255) & ~(size_t)255);
     }
+    c->opt_dev_presolve = !(getenv("LORADS_DEV_PRESOLVE") && getenv("LORADS_DEV_PRESOLVE")[0] == '0');
+    c->opt_presolve_check = getenv("LORADS_PRESOLVE_CHECK") && getenv("LORADS_PRESOLVE_CHECK")[0] == '1';
+    if (getenv("LORADS_DEV_PRESOLVE_MIN")) c->dev_presolve_min = (size_t)std::max(0ll, atoll(getenv("LORADS_DEV_PRESOLVE_MIN")));
     c->blk.resize(c->nb);
     for (int k = 0; k < c->nb; ++k)
         if (build_block(c, c->blk[k], prob->blocks[k])) { lorads_hip_destroy(c); return 1; }
@@ -1395,6 +1402,12 @@ int lorads_hip_block_image(lorads_hip_ctx *c, int32_t k, int64_t im[16]) {
     const int64_t v[16] = {B.n, B.r, B.nrow, B.na, B.nc, B.pa.ne, B.pu.ne, B.dense_c, B.dense_a ? B.nd : 0, B.diag_only, B.entry_only,
                            B.use_cw, B.has_gram, B.front_cw, B.cell_w, B.bip_n[0]};
     for (int i = 0; i < 16; ++i) im[i] = v[i];
+    return 0;
+}
+
+int lorads_hip_presolve_stats(lorads_hip_ctx *c, int64_t stats[2]) {
+    stats[0] = c->n_dev_patterns;
+    stats[1] = c->n_checked_patterns;
     return 0;
 }
 

@@ -450,6 +450,14 @@ class Session:
         _check(lib.lorads_hip_graph_stats(ctx, out), "graph_stats")
         return dict(zip(["captured", "replayed", "held", "enabled"], [int(out[i]) for i in range(4)]))
 
+    def hip_presolve_stats(self):
+        """{device: patterns built by the device sorts, checked: of these compared with the host construction}"""
+        lib, ctx = self._hip()
+        out = (C.c_int64 * 2)()
+        lib.lorads_hip_presolve_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_presolve_stats(ctx, out), "presolve_stats")
+        return {"device": int(out[0]), "checked": int(out[1])}
+
     def hip_operator_kind(self, blk=0):
         lib, ctx = self._hip()
         k = C.c_int()

@@ -89,3 +89,48 @@ def test_device_image_matches_the_reference(built, case):
                 assert not im["diag_only"] and not im["entry_only"] and not im["dense_a"] and im["nrow"] >= 256
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in CASES if c.endswith("@2.0")])
+def test_device_sorts_build_the_host_patterns_small(built, case, monkeypatch):
+    """The pattern work on the device (csrc/hip/presolve.inc: radix sorts + scans for the unique positions, the adjacency, the
+    transpose of the constraint CSR) against the host construction it replaces, array by array, on every golden instance -- LP
+    blocks, dense coefficients, empty cones, one-row cones included.  LORADS_PRESOLVE_CHECK=1 makes lorads_hip_create build both
+    and refuse any difference; LORADS_DEV_PRESOLVE_MIN=0 sends even these small patterns through the device code."""
+    monkeypatch.setenv("LORADS_PRESOLVE_CHECK", "1")
+    monkeypatch.setenv("LORADS_DEV_PRESOLVE_MIN", "0")
+    name, tlr = case.split("@")
+    s = common.hip_session(common.instance_path(name), timesLogRank=float(tlr))
+    try:
+        st = s.hip_presolve_stats()
+        assert st["device"] >= 2 and st["checked"] == st["device"], st      # (A-pattern and union pattern of every cone)
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["rand20000", "maxcut20000", "blk16x4000", "matcomp50000"])
+def test_device_sorts_build_the_host_patterns_fullsize(built, name, monkeypatch):
+    """The same comparison at BASELINE's sizes, with the default threshold (these patterns are the ones the device builds in a
+    normal run), and the device image that comes out equals the one of a host-built context."""
+    from tests.test_hip_parity import _gen
+    path = _gen(name)
+    images = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("LORADS_PRESOLVE_CHECK", "1" if mode == "device" else "0")
+        monkeypatch.setenv("LORADS_DEV_PRESOLVE", "1" if mode == "device" else "0")
+        if name == "blk16x4000":       # (16 cones of ~10^4 stored entries each: below the default threshold)
+            monkeypatch.setenv("LORADS_DEV_PRESOLVE_MIN", "4096")
+        s = common.hip_session(path)
+        try:
+            st = s.hip_presolve_stats()
+            if mode == "device":
+                assert st["device"] >= 1 and st["checked"] == st["device"], st      # (Max-Cut's A-pattern is its diagonal: host)
+            else:
+                assert st["device"] == 0
+            images[mode] = [s.hip_block_image(k) for k in range(s.nblk)]
+        finally:
+            s.close()
+    assert images["device"] == images["host"]
