@@ -201,6 +201,11 @@ void lrd_params_default(lrd_params *p);
 int lrd_params_set(lrd_params *p, const char *key, const char *val); /* reference CLI names, main.c:57-80 */
 /* SDPA sparse reader (own implementation; conventions of src_semi/io/lorads_file_io.c:21-293). */
 int lrd_read_sdpa(const char *fname, lrd_problem **out);
+/* one entry line of an SDPA file, "mat blk i j value": returns the number of fields found (5 = a full entry), exactly as
+ * sscanf("%d %d %d %d %lg") would; the value is converted as strtod converts it (problem.c; exported for the tests) */
+int lrd_parse_entry_line(const char *line, int ij[4], double *val);
+/* digest of the whole image (dimensions, every array, norms): equal digests = the same problem */
+uint64_t lrd_problem_digest(const lrd_problem *p);
 /* Build a problem from arrays (bench / tests; 0-based mat: 0 = F0, blk, row, col); same
  * post-processing as the reader (F0 negated, lower triangle, tiny entries dropped, pre-solve). */
 int lrd_problem_from_triplets(int m, const double *b, int nblk, const int *dims, int64_t nent, const int *e_mat,

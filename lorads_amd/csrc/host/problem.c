@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef struct {
     int mat, blk, row, col;
@@ -36,22 +37,34 @@ typedef struct {
     int row, col;
 } pos_t;
 
-static int pos_cmp(const void *pa, const void *pb) {
-    const pos_t *a = (const pos_t *)pa, *b = (const pos_t *)pb;
-    if (a->col != b->col) return a->col < b->col ? -1 : 1;
-    return (a->row > b->row) - (a->row < b->row);
-}
-
-static int pos_find(const pos_t *u, int np, int row, int col) {
-    int lo = 0, hi = np - 1;
-    while (lo <= hi) {
-        int mid = (lo + hi) / 2;
-        if (u[mid].col < col || (u[mid].col == col && u[mid].row < row)) lo = mid + 1;
-        else if (u[mid].col == col && u[mid].row == row) return mid;
-        else hi = mid - 1;
+/* stable LSD radix sort of n (key, payload) pairs on the low `bits` bits of the keys, 11 bits per pass (the qsort calls this replaces
+ * were the larger half of the reader's time on files of 10^5+ entries).  Returns 0, or 1 when the scratch could not be allocated */
+static int radix_pairs(uint64_t *key, uint32_t *val, size_t n, int bits) {
+    if (n < 2) return 0;
+    uint64_t *k2 = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint32_t *v2 = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    size_t *cnt = (size_t *)malloc(sizeof(size_t) * 2048);
+    if (!k2 || !v2 || !cnt) { free(k2); free(v2); free(cnt); return 1; }
+    uint64_t *ka = key, *kb = k2;
+    uint32_t *va = val, *vb = v2;
+    for (int shift = 0; shift < bits; shift += 11) {
+        memset(cnt, 0, sizeof(size_t) * 2048);
+        for (size_t i = 0; i < n; ++i) cnt[(ka[i] >> shift) & 2047u]++;
+        if (cnt[(ka[0] >> shift) & 2047u] == n) continue; /* (all keys share this digit) */
+        size_t run = 0;
+        for (int d = 0; d < 2048; ++d) { const size_t c = cnt[d]; cnt[d] = run; run += c; }
+        for (size_t i = 0; i < n; ++i) {
+            const size_t dst = cnt[(ka[i] >> shift) & 2047u]++;
+            kb[dst] = ka[i]; vb[dst] = va[i];
+        }
+        uint64_t *tk = ka; ka = kb; kb = tk;
+        uint32_t *tv = va; va = vb; vb = tv;
     }
-    return -1;
+    if (ka != key) { memcpy(key, ka, sizeof(uint64_t) * n); memcpy(val, va, sizeof(uint32_t) * n); }
+    free(k2); free(v2); free(cnt);
+    return 0;
 }
+static int bits_of(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
 
 static void block_free(lrd_block *b) {
     free(b->row_idx); free(b->a_ptr); free(b->a_row); free(b->a_col); free(b->a_val);
@@ -84,15 +97,27 @@ static int block_presolve(lrd_block *b, int m) {
     }
     pos_t *u = NULL;
     int np = 0;
+    uint32_t *who = NULL; /* sorted position -> stored entry (C's first, then the A_i's) */
+    int *upos = NULL;     /* sorted position -> its place in the union pattern */
     if (!dense) {
-        int tot = b->c_nnz + na;
-        u = (pos_t *)malloc(sizeof(pos_t) * (size_t)(tot > 0 ? tot : 1));
-        for (int k = 0; k < b->c_nnz; ++k) { u[k].row = b->c_row[k]; u[k].col = b->c_col[k]; }
-        for (int k = 0; k < na; ++k) { u[b->c_nnz + k].row = b->a_row[k]; u[b->c_nnz + k].col = b->a_col[k]; }
-        qsort(u, (size_t)tot, sizeof(pos_t), pos_cmp);
-        for (int k = 0; k < tot; ++k)
-            if (k == 0 || u[k].row != u[k - 1].row || u[k].col != u[k - 1].col) u[np++] = u[k];
-        if ((double)np / (double)npack >= 0.1 && !b->is_lp) { dense = 1; free(u); u = NULL; }
+        const int tot = b->c_nnz + na;
+        const size_t cap = (size_t)(tot > 0 ? tot : 1);
+        u = (pos_t *)malloc(sizeof(pos_t) * cap);
+        uint64_t *key = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+        who = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+        upos = (int *)malloc(sizeof(int) * cap);
+        if (!u || !key || !who || !upos) { free(u); free(key); free(who); free(upos); return 1; }
+        const uint64_t nn = (uint64_t)(n > 0 ? n : 1);
+        for (int k = 0; k < b->c_nnz; ++k) key[k] = (uint64_t)b->c_col[k] * nn + (uint64_t)b->c_row[k];
+        for (int k = 0; k < na; ++k) key[b->c_nnz + k] = (uint64_t)b->a_col[k] * nn + (uint64_t)b->a_row[k];
+        for (int k = 0; k < tot; ++k) who[k] = (uint32_t)k;
+        if (radix_pairs(key, who, (size_t)tot, bits_of(nn * nn))) { free(u); free(key); free(who); free(upos); return 1; } /* by column, then row */
+        for (int k = 0; k < tot; ++k) {
+            if (k == 0 || key[k] != key[k - 1]) { u[np].row = (int)(key[k] % nn); u[np].col = (int)(key[k] / nn); ++np; }
+            upos[k] = np - 1;
+        }
+        free(key);
+        if ((double)np / (double)npack >= 0.1 && !b->is_lp) { dense = 1; free(u); u = NULL; free(who); who = NULL; free(upos); upos = NULL; }
     }
     b->dense_mode = dense;
     free(b->p_row); free(b->p_col); free(b->a_pidx); free(b->c_pidx);
@@ -116,9 +141,12 @@ static int block_presolve(lrd_block *b, int m) {
         b->p_row = (int *)malloc(sizeof(int) * (size_t)(np > 0 ? np : 1));
         b->p_col = (int *)malloc(sizeof(int) * (size_t)(np > 0 ? np : 1));
         for (int k = 0; k < np; ++k) { b->p_row[k] = u[k].row; b->p_col[k] = u[k].col; }
-        for (int k = 0; k < na; ++k) b->a_pidx[k] = pos_find(u, np, b->a_row[k], b->a_col[k]);
-        for (int k = 0; k < b->c_nnz; ++k) b->c_pidx[k] = pos_find(u, np, b->c_row[k], b->c_col[k]);
-        free(u);
+        for (int k = 0; k < b->c_nnz + na; ++k) { /* every stored entry's place in the pattern, from the sort's payload */
+            const int w = (int)who[k];
+            if (w < b->c_nnz) b->c_pidx[w] = upos[k];
+            else b->a_pidx[w - b->c_nnz] = upos[k];
+        }
+        free(u); free(who); free(upos);
     }
     return 0;
 }
@@ -146,6 +174,37 @@ static void problem_norms(lrd_problem *p) {
         if (a > binf) binf = a;
     }
     p->bNrm1 = b1; p->bNrm2 = sqrt(b2); p->bNrmInf = binf;
+}
+
+/* entries into (cone, matrix, column, row, file order): two radix sorts on packed keys -- (column, row) first, (cone, matrix) second,
+ * both stable, starting from file order -- and one gather; qsort with ent_cmp when the keys do not pack (or LORADS_READER=sscanf: tests) */
+static int sort_entries(ent_t *e, int64_t ne, int nblk, int m, const lrd_problem *p) {
+    uint64_t nmax = 1;
+    for (int k = 0; k < nblk; ++k)
+        if ((uint64_t)p->blk[k].n > nmax) nmax = (uint64_t)p->blk[k].n;
+    const int plain = getenv("LORADS_READER") && !strcmp(getenv("LORADS_READER"), "sscanf");
+    if (plain || ne < 2 || ne > 0xffffffffll || nmax > 0x7fffffffull || (uint64_t)nblk * ((uint64_t)m + 1) > ((uint64_t)1 << 62)) {
+        qsort(e, (size_t)ne, sizeof(ent_t), ent_cmp);
+        return 0;
+    }
+    uint64_t *key = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)ne);
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)ne);
+    ent_t *tmp = (ent_t *)malloc(sizeof(ent_t) * (size_t)ne);
+    int rc = !key || !idx || !tmp;
+    if (!rc) {
+        for (int64_t t = 0; t < ne; ++t) { key[t] = (uint64_t)e[t].col * nmax + (uint64_t)e[t].row; idx[t] = (uint32_t)t; }
+        rc = radix_pairs(key, idx, (size_t)ne, bits_of(nmax * nmax));
+    }
+    if (!rc) {
+        for (int64_t t = 0; t < ne; ++t) key[t] = (uint64_t)e[idx[t]].blk * ((uint64_t)m + 1) + (uint64_t)e[idx[t]].mat;
+        rc = radix_pairs(key, idx, (size_t)ne, bits_of((uint64_t)nblk * ((uint64_t)m + 1)));
+    }
+    if (!rc) {
+        for (int64_t t = 0; t < ne; ++t) tmp[t] = e[idx[t]];
+        memcpy(e, tmp, sizeof(ent_t) * (size_t)ne);
+    }
+    free(key); free(idx); free(tmp);
+    return rc;
 }
 
 /* shared back end of the reader and of lrd_problem_from_triplets: entries are 0-based, mat 0 = F0 */
@@ -178,7 +237,7 @@ static int build_problem(int m, const double *bvec, int nblk, const int *dims, e
         e[w++] = x;
     }
     ne = w;
-    qsort(e, (size_t)ne, sizeof(ent_t), ent_cmp);
+    if (sort_entries(e, ne, nblk, m, p)) { lrd_problem_free(p); return 3; }
     int64_t pos = 0;
     for (int k = 0; k < nblk; ++k) {
         lrd_block *b = &p->blk[k];
@@ -230,55 +289,150 @@ int lrd_problem_from_triplets(int m, const double *b, int nblk, const int *dims,
     return rc;
 }
 
-/* ---- SDPA sparse format ---- */
-static char *read_line_dyn(FILE *f, char **buf, size_t *cap) {
-    size_t len = 0;
-    int ch;
-    if (!*buf) { *cap = 4096; *buf = (char *)malloc(*cap); }
-    while ((ch = fgetc(f)) != EOF) {
-        if (len + 2 > *cap) { *cap *= 2; *buf = (char *)realloc(*buf, *cap); }
-        (*buf)[len++] = (char)ch;
-        if (ch == '\n') break;
-    }
-    if (len == 0 && ch == EOF) return NULL;
-    (*buf)[len] = 0;
-    return *buf;
+/* ---- SDPA sparse format ----
+ * The file is read in one piece and scanned in place.  Entry lines ("mat blk i j value", the bulk of any file) go through a parser of
+ * their own instead of sscanf: four decimal integers and a value whose conversion is EXACTLY strtod's -- a decimal token of at most
+ * 19 significant digits whose mantissa fits 2^53 and whose power of ten is within 10^+-22 is one exact integer times or over one exact
+ * power of ten, i.e. one correctly rounded IEEE operation (Clinger's fast path); everything else (longer mantissas, big exponents,
+ * inf / nan / hex) is handed to strtod itself.  Same values bit for bit, ~4x less time per line (io/lorads_file_io.c:21-293 uses fscanf). */
+typedef struct {
+    char *p, *end; /* cursor and one past the last byte of the file (the byte at `end` is a NUL we own) */
+} scan_t;
+
+/* next line, NUL-terminated in place (the '\n' is overwritten); NULL at the end of the file */
+static char *next_line(scan_t *sc) {
+    if (sc->p >= sc->end) return NULL;
+    char *ln = sc->p;
+    char *nl = (char *)memchr(ln, '\n', (size_t)(sc->end - ln));
+    if (nl) { *nl = 0; sc->p = nl + 1; }
+    else sc->p = sc->end;
+    return ln;
 }
 
 /* numbers separated by anything that is not part of a number ({ } ( ) , ' and blanks) */
+static int scan_double(const char **sp, double *out);
 static int next_number(char **s, double *v) {
     char *c = *s;
     while (*c && !(isdigit((unsigned char)*c) || *c == '-' || *c == '+' || *c == '.')) ++c;
     if (!*c) { *s = c; return 0; }
-    char *end;
-    *v = strtod(c, &end);
-    if (end == c) { *s = c + 1; return next_number(s, v); }
-    *s = end;
+    const char *end = c;
+    if (!scan_double(&end, v)) { *s = c + 1; return next_number(s, v); }
+    *s = (char *)end;
     return 1;
 }
 
+static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20,
+                               1e21, 1e22};
+
+/* "%d": optional blanks, optional sign, digits.  Returns 0 when there is no integer here (as a failed sscanf field) */
+static int scan_int(const char **sp, int *out) {
+    const char *s = *sp;
+    while (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\v' || *s == '\f') ++s;
+    int neg = 0;
+    if (*s == '-') { neg = 1; ++s; }
+    else if (*s == '+') ++s;
+    if (!isdigit((unsigned char)*s)) return 0;
+    long long v = 0;
+    while (isdigit((unsigned char)*s)) { v = v * 10 + (*s - '0'); if (v > 4000000000ll) return 0; ++s; }
+    *out = (int)(neg ? -v : v);
+    *sp = s;
+    return 1;
+}
+
+/* "%lg": the value of the token at *sp exactly as strtod converts it.  Returns 0 when there is no number */
+static int scan_double(const char **sp, double *out) {
+    const char *s = *sp;
+    while (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\v' || *s == '\f') ++s;
+    const char *t = s;
+    int neg = 0;
+    if (*t == '-') { neg = 1; ++t; }
+    else if (*t == '+') ++t;
+    unsigned long long mant = 0;
+    int nsig = 0, e10 = 0, ndig = 0, fast = 1;
+    while (isdigit((unsigned char)*t)) {
+        if (nsig < 19) { mant = mant * 10 + (unsigned)(*t - '0'); if (mant) ++nsig; }
+        else fast = 0; /* (a 20th significant digit: strtod decides the rounding) */
+        ++t; ++ndig;
+    }
+    if (*t == '.') {
+        ++t;
+        while (isdigit((unsigned char)*t)) {
+            if (nsig < 19) { mant = mant * 10 + (unsigned)(*t - '0'); if (mant) ++nsig; --e10; }
+            else fast = 0;
+            ++t; ++ndig;
+        }
+    }
+    if (ndig > 0 && (*t == 'e' || *t == 'E')) {
+        const char *u = t + 1;
+        int eneg = 0, ev = 0, ed = 0;
+        if (*u == '-') { eneg = 1; ++u; }
+        else if (*u == '+') ++u;
+        while (isdigit((unsigned char)*u)) { if (ev < 100000) ev = ev * 10 + (*u - '0'); ++u; ++ed; }
+        if (ed) { e10 += eneg ? -ev : ev; t = u; }
+    }
+    /* the short way only for a plain decimal token that ends where a number ends */
+    if (fast && ndig > 0 && !isalnum((unsigned char)*t) && *t != '.' && mant <= (1ull << 53) && e10 >= -22 && e10 <= 22) {
+        double v = (double)mant;
+        if (e10 < 0) v /= P10[-e10];
+        else v *= P10[e10];
+        *out = neg ? -v : v;
+        *sp = t;
+        return 1;
+    }
+    char *end;
+    const double v = strtod(s, &end);
+    if (end == s) return 0;
+    *out = v;
+    *sp = end;
+    return 1;
+}
+
+/* one entry line: 5 = all fields there (what sscanf("%d %d %d %d %lg") returns for it), less otherwise.  Exported for the tests */
+int lrd_parse_entry_line(const char *line, int ij[4], double *val) {
+    const char *s = line;
+    for (int k = 0; k < 4; ++k)
+        if (!scan_int(&s, &ij[k])) return k;
+    return scan_double(&s, val) ? 5 : 4;
+}
+
 int lrd_read_sdpa(const char *fname, lrd_problem **out) {
-    FILE *f = fopen(fname, "r");
+    FILE *f = fopen(fname, "rb");
     if (!f) return 1;
-    char *buf = NULL;
-    size_t cap = 0;
-    char *ln;
+    char *ln, *text = NULL;
     int rc = 2, m = -1, nblk = -1, *dims = NULL;
     double *b = NULL, v;
     ent_t *e = NULL;
     int64_t ne = 0, ecap = 0;
+    size_t len = 0, cap = (size_t)1 << 20;
+    text = (char *)malloc(cap + 1);
+    for (;;) { /* (grows by doubling: works for pipes too) */
+        const size_t got = text ? fread(text + len, 1, cap - len, f) : 0;
+        len += got;
+        if (!text || got == 0) break;
+        if (len == cap) { cap *= 2; text = (char *)realloc(text, cap + 1); }
+    }
+    fclose(f);
+    if (!text) return 2;
+    text[len] = 0;
+    for (size_t i = 0; i < len; ++i) /* a stray NUL would end a line early: the old line reader stopped at it too; make it a blank */
+        if (!text[i]) text[i] = ' ';
+    scan_t sc = {text, text + len};
+    const int timing = getenv("LORADS_HOST_TIMING") != NULL; /* stage times of the reader on stderr */
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int use_sscanf = getenv("LORADS_READER") && !strcmp(getenv("LORADS_READER"), "sscanf"); /* (the former per-line conversion: tests) */
     /* header: skip comment lines (first char '*' or '"') */
-    do { ln = read_line_dyn(f, &buf, &cap); } while (ln && (ln[0] == '*' || ln[0] == '"'));
+    do { ln = next_line(&sc); } while (ln && (ln[0] == '*' || ln[0] == '"'));
     if (!ln) goto done;
     { char *s = ln; if (!next_number(&s, &v)) goto done; m = (int)v; }
-    ln = read_line_dyn(f, &buf, &cap);
+    ln = next_line(&sc);
     if (!ln) goto done;
     { char *s = ln; if (!next_number(&s, &v)) goto done; nblk = (int)v; }
     if (m < 0 || nblk <= 0) goto done;
     dims = (int *)malloc(sizeof(int) * (size_t)nblk);
     { int got = 0;
       while (got < nblk) {
-          ln = read_line_dyn(f, &buf, &cap);
+          ln = next_line(&sc);
           if (!ln) goto done;
           char *s = ln;
           while (got < nblk && next_number(&s, &v)) dims[got++] = (int)v;
@@ -288,29 +442,70 @@ int lrd_read_sdpa(const char *fname, lrd_problem **out) {
     b = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
     { int got = 0;
       while (got < m) {
-          ln = read_line_dyn(f, &buf, &cap);
+          ln = next_line(&sc);
           if (!ln) goto done;
           char *s = ln;
           while (got < m && next_number(&s, &v)) b[got++] = v;
       } }
-    while ((ln = read_line_dyn(f, &buf, &cap)) != NULL) {
-        int mat, blk, i, j;
+    while ((ln = next_line(&sc)) != NULL) {
+        int ij[4];
         double val;
-        if (sscanf(ln, "%d %d %d %d %lg", &mat, &blk, &i, &j, &val) != 5) {
+        const int nf = use_sscanf ? sscanf(ln, "%d %d %d %d %lg", &ij[0], &ij[1], &ij[2], &ij[3], &val) : lrd_parse_entry_line(ln, ij, &val);
+        if (nf != 5) {
             char *s = ln;
             while (*s && isspace((unsigned char)*s)) ++s;
             if (!*s) continue;
             break; /* trailing comment section */
         }
         if (ne == ecap) { ecap = ecap ? 2 * ecap : 1 << 16; e = (ent_t *)realloc(e, sizeof(ent_t) * (size_t)ecap); }
-        e[ne].mat = mat; e[ne].blk = blk - 1; e[ne].row = i - 1; e[ne].col = j - 1; e[ne].val = val; e[ne].seq = ne;
+        e[ne].mat = ij[0]; e[ne].blk = ij[1] - 1; e[ne].row = ij[2] - 1; e[ne].col = ij[3] - 1; e[ne].val = val; e[ne].seq = ne;
         ++ne;
     }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     rc = build_problem(m, b, nblk, dims, e, ne, out);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (timing)
+        fprintf(stderr, "lorads_host: reader: %lld entry lines scanned in %.1f ms, problem image (sort, cones, pre-solve) %.1f ms\n", (long long)ne,
+                1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec),
+                1e3 * (double)(t2.tv_sec - t1.tv_sec) + 1e-6 * (double)(t2.tv_nsec - t1.tv_nsec));
 done:
-    fclose(f);
-    free(buf); free(dims); free(b); free(e);
+    free(text); free(dims); free(b); free(e);
     return rc;
+}
+
+/* FNV-1a over everything the image holds (dimensions, every array, the norms): two images with the same digest are the same
+ * problem (used by the tests to compare the reader's two conversion paths) */
+static uint64_t fnv(uint64_t h, const void *data, size_t bytes) {
+    const unsigned char *c = (const unsigned char *)data;
+    for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+uint64_t lrd_problem_digest(const lrd_problem *p) {
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, &p->m, sizeof p->m);
+    h = fnv(h, &p->nblk, sizeof p->nblk);
+    h = fnv(h, p->b, sizeof(double) * (size_t)p->m);
+    const double nr[6] = {p->cObjNrm1, p->cObjNrm2, p->cObjNrmInf, p->bNrm1, p->bNrm2, p->bNrmInf};
+    h = fnv(h, nr, sizeof nr);
+    for (int k = 0; k < p->nblk; ++k) {
+        const lrd_block *b = &p->blk[k];
+        const int hd[8] = {b->n, b->nrow, b->c_nnz, b->cone_sparse, b->dense_mode, b->np, b->is_lp, b->global_id};
+        h = fnv(h, hd, sizeof hd);
+        const size_t na = (size_t)b->a_ptr[b->nrow];
+        h = fnv(h, b->row_idx, sizeof(int) * (size_t)b->nrow);
+        h = fnv(h, b->a_ptr, sizeof(int) * ((size_t)b->nrow + 1));
+        h = fnv(h, b->a_row, sizeof(int) * na);
+        h = fnv(h, b->a_col, sizeof(int) * na);
+        h = fnv(h, b->a_val, sizeof(double) * na);
+        h = fnv(h, b->c_row, sizeof(int) * (size_t)b->c_nnz);
+        h = fnv(h, b->c_col, sizeof(int) * (size_t)b->c_nnz);
+        h = fnv(h, b->c_val, sizeof(double) * (size_t)b->c_nnz);
+        h = fnv(h, b->p_row, sizeof(int) * (size_t)b->np);
+        h = fnv(h, b->p_col, sizeof(int) * (size_t)b->np);
+        h = fnv(h, b->a_pidx, sizeof(int) * na);
+        h = fnv(h, b->c_pidx, sizeof(int) * (size_t)b->c_nnz);
+    }
+    return h;
 }
 
 void lrd_problem_select(lrd_problem *p, const int *keep) {
