@@ -206,6 +206,8 @@ int lrd_read_sdpa(const char *fname, lrd_problem **out);
 int lrd_parse_entry_line(const char *line, int ij[4], double *val);
 /* digest of the whole image (dimensions, every array, norms): equal digests = the same problem */
 uint64_t lrd_problem_digest(const lrd_problem *p);
+/* 1 when the start point is drawn by the inline copy of glibc's rand() recurrence (verified against rand() at run time), 0 when by rand() */
+int lrd_start_generator_is_inline(void);
 /* Build a problem from arrays (bench / tests; 0-based mat: 0 = F0, blk, row, col); same
  * post-processing as the reader (F0 negated, lower triangle, tiny entries dropped, pre-solve). */
 int lrd_problem_from_triplets(int m, const double *b, int nblk, const int *dims, int64_t nent, const int *e_mat,

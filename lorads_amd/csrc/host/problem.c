@@ -583,18 +583,76 @@ void lrd_determine_rank(lrd_problem *p, double times) {
     }
 }
 
+/* The start point is the reference's: srand(925), then two rand() draws per element, R of every cone first, then U and V cone by
+ * cone (data/lorads_solver.c:361-371,415,652-653).  glibc's rand() is the TYPE_3 additive-feedback generator behind a lock
+ * (r[i] = r[i-3] + r[i-31] mod 2^32, output r[i] >> 1, state seeded by the Lehmer generator 16807 mod 2^31 - 1 and run 310 steps): the
+ * same recurrence inline draws the 2 x 3 x n x r numbers of cfg5 in 0.03 s instead of 0.19.  It is used only when its first 4096
+ * outputs equal this C library's rand() -- on a platform whose rand() is another generator the library's own is called, as the
+ * reference would there. */
+typedef struct {
+    uint32_t r[34];
+    int i; /* next write position in the ring of 34 (holds r[k-31..k-1] and r[k-3]) */
+    int use_libc;
+} rng_t;
+static uint32_t rng_next_raw(rng_t *g) { /* one step of r[k] = r[k-31] + r[k-3] on a ring of 31 */
+    const int k = g->i;
+    const uint32_t v = g->r[k] + g->r[(k + 28) % 31]; /* r[k-31] sits in slot k, r[k-3] in slot k-3 = k+28 mod 31 */
+    g->r[k] = v;
+    g->i = (k + 1) % 31;
+    return v;
+}
+static void rng_seed_glibc(rng_t *g, unsigned seed) {
+    int32_t st[34];
+    st[0] = (int32_t)(seed ? seed : 1);
+    for (int i = 1; i < 31; ++i) {
+        const long hi = st[i - 1] / 127773, lo = st[i - 1] % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        st[i] = (int32_t)w;
+    }
+    /* glibc keeps r[0..30] in a ring with the front pointer at 3 and the rear at 0, and discards 310 outputs */
+    for (int i = 0; i < 31; ++i) g->r[i] = (uint32_t)st[i];
+    /* in sequence terms: r[31 + j] = r[j] for j = 0..2 (front starts three ahead), then the recurrence.  Rotate so that slot 0 holds the
+     * oldest value the recurrence needs: after the three copies the window is r[3..33] = st[3..30], st[0..2] */
+    uint32_t win[31];
+    for (int i = 0; i < 28; ++i) win[i] = (uint32_t)st[i + 3];
+    for (int i = 0; i < 3; ++i) win[28 + i] = (uint32_t)st[i];
+    memcpy(g->r, win, sizeof win);
+    g->i = 0;
+    for (int i = 0; i < 310; ++i) (void)rng_next_raw(g);
+}
+static void rng_init(rng_t *g, unsigned seed) {
+    g->use_libc = 0;
+    rng_seed_glibc(g, seed);
+    rng_t probe = *g;
+    srand(seed);
+    for (int i = 0; i < 4096 && !g->use_libc; ++i)
+        if ((int)(rng_next_raw(&probe) >> 1) != rand()) g->use_libc = 1;
+    if (getenv("LORADS_LIBC_RAND")) g->use_libc = 1; /* (tests) */
+    srand(seed); /* (the library's generator starts over for the path that uses it) */
+}
+static inline int rng_rand(rng_t *g) { return g->use_libc ? rand() : (int)(rng_next_raw(g) >> 1); }
+
+/* 1: the inline generator reproduces this C library's rand() (and is the one lrd_init_point draws from); 0: rand() itself is used */
+int lrd_start_generator_is_inline(void) {
+    rng_t g;
+    rng_init(&g, 925);
+    return !g.use_libc;
+}
+
 int lrd_init_point(const lrd_problem *p, double ***Rp, double ***Up, double ***Vp) {
     int nb = p->nblk;
     double **R = (double **)calloc((size_t)nb, sizeof(double *));
     double **U = (double **)calloc((size_t)nb, sizeof(double *));
     double **V = (double **)calloc((size_t)nb, sizeof(double *));
-    srand(925);
+    rng_t g;
+    rng_init(&g, 925);
     for (int k = 0; k < nb; ++k) {
         size_t cnt = (size_t)p->blk[k].n * p->blk[k].rank;
         R[k] = (double *)malloc(sizeof(double) * cnt);
         for (size_t i = 0; i < cnt; ++i) {
-            double x = (double)rand() / RAND_MAX;
-            x -= (double)rand() / RAND_MAX;
+            double x = (double)rng_rand(&g) / RAND_MAX;
+            x -= (double)rng_rand(&g) / RAND_MAX;
             R[k][i] = x;
         }
     }
@@ -602,8 +660,8 @@ int lrd_init_point(const lrd_problem *p, double ***Rp, double ***Up, double ***V
         size_t cnt = (size_t)p->blk[k].n * p->blk[k].rank;
         U[k] = (double *)malloc(sizeof(double) * cnt);
         V[k] = (double *)malloc(sizeof(double) * cnt);
-        for (size_t i = 0; i < cnt; ++i) { double x = (double)rand() / RAND_MAX; x -= (double)rand() / RAND_MAX; U[k][i] = x; }
-        for (size_t i = 0; i < cnt; ++i) { double x = (double)rand() / RAND_MAX; x -= (double)rand() / RAND_MAX; V[k][i] = x; }
+        for (size_t i = 0; i < cnt; ++i) { double x = (double)rng_rand(&g) / RAND_MAX; x -= (double)rng_rand(&g) / RAND_MAX; U[k][i] = x; }
+        for (size_t i = 0; i < cnt; ++i) { double x = (double)rng_rand(&g) / RAND_MAX; x -= (double)rng_rand(&g) / RAND_MAX; V[k][i] = x; }
     }
     *Rp = R; *Up = U; *Vp = V;
     return 0;

@@ -158,3 +158,32 @@ def test_same_problem_on_a_large_generated_file(tmp_path):
     big = str(tmp_path / "rand4000.dat-s")
     instances.write_sdpa(instances.NAMED["rand4000"](), big)
     assert _digest(big, "fast") == _digest(big, "sscanf")
+
+
+def test_start_point_generator_is_the_c_librarys(monkeypatch):
+    """lrd_init_point draws the reference's start point (srand(925); two rand() per element, data/lorads_solver.c:361-371) from an inline
+    copy of glibc's recurrence; the same numbers as rand() itself, element by element, on a multi-cone instance with an LP block"""
+    lib = host.host_lib()
+    assert lib.lrd_start_generator_is_inline() == 1
+    pts = {}
+    for mode in ("inline", "libc"):
+        if mode == "libc":
+            monkeypatch.setenv("LORADS_LIBC_RAND", "1")
+        s = host.Session.open(common.instance_path("sdplp40"))
+        s.set_params(verbose=0)
+        s.prepare(1, 0)
+        pts[mode] = [s.start_point(w, k) for k in range(s.nblk) for w in range(3)]
+        s.close()
+    assert len(pts["inline"]) >= 6
+    for a, b in zip(pts["inline"], pts["libc"]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    s = host.Session.open(common.instance_path("maxcut800"))
+    s.set_params(verbose=0, timesLogRank=6.0)
+    s.prepare(1, 0)
+    monkeypatch.delenv("LORADS_LIBC_RAND")
+    t = host.Session.open(common.instance_path("maxcut800"))
+    t.set_params(verbose=0, timesLogRank=6.0)
+    t.prepare(1, 0)
+    for w in range(3):
+        assert np.array_equal(s.start_point(w, 0), t.start_point(w, 0))
+    s.close(); t.close()
