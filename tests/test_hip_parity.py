@@ -877,9 +877,11 @@ def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_laun
         path = common.instance_path(name)
     res = []
     # (carried by the next operator kernel -- the default; on the update's last workgroup; a launch of its own)
-    for carry, lastblock in (("1", "0"), ("0", "1"), ("0", "0")):
+    # (... ; the same with the k % 20 == 0 restart's test and scalars as launches of their own -- round 2's form)
+    for carry, lastblock, restart in (("1", "0", "1"), ("0", "1", "1"), ("0", "0", "1"), ("1", "0", "0")):
         monkeypatch.setenv("LORADS_SEG_CARRY", carry)
         monkeypatch.setenv("LORADS_SEG_LASTBLOCK", lastblock)
+        monkeypatch.setenv("LORADS_SEG_CARRY_RESTART", restart)
         params = dict(phase1Tol=1e-1) if tlr is None else dict(phase1Tol=1e-1, timesLogRank=tlr)
         s = common.hip_session(path, **params)
         try:
