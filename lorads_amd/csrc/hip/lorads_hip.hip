@@ -565,6 +565,8 @@ struct lorads_hip_ctx {
                      const double *rs_seg = nullptr; } pend_dir; // rs_seg: lockstep restart's scalars riding with it (chk_tol / chk_maxit / chk_k set too)
     struct PendSegChk { bool on = false; int half = 0, k = 0; const double *part = nullptr; double tol = 0; int maxit = 0;
                         bool ride_res = false; } pend_segchk; // ride_res: the restart's residual pass that follows may take it (see op_diag)
+    struct PendSegInit { bool on = false; int half = 0; double tol = 0; Guard front{}; const double *part_rr = nullptr, *part_b = nullptr; } pend_seginit; // lockstep sweep: the solves' start waiting for iteration 0's operator kernel
+    bool opt_seg_carry_init = true; // (LORADS_SEG_CARRY_INIT=0: k_cg_init_seg as a launch of its own)
     bool opt_seg_carry_restart = true; // lockstep sweep: the k % 20 == 0 restart's test and scalars ride on its two operator kernels (LORADS_SEG_CARRY_RESTART=0)
     double *seg_rr_alt = nullptr; // second slot of every stage's r.r (see SegArgs)
     int *seg_tile_info = nullptr; // int4 per row tile of the merged cone (see DirArgs.seg_info)
@@ -696,6 +698,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
     c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
+    c->opt_seg_carry_init = !(getenv("LORADS_SEG_CARRY_INIT") && getenv("LORADS_SEG_CARRY_INIT")[0] == '0');
     c->opt_seg_carry_restart = !(getenv("LORADS_SEG_CARRY_RESTART") && getenv("LORADS_SEG_CARRY_RESTART")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');

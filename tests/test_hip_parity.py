@@ -878,10 +878,13 @@ def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_laun
     res = []
     # (carried by the next operator kernel -- the default; on the update's last workgroup; a launch of its own)
     # (... ; the same with the k % 20 == 0 restart's test and scalars as launches of their own -- round 2's form)
-    for carry, lastblock, restart in (("1", "0", "1"), ("0", "1", "1"), ("0", "0", "1"), ("1", "0", "0")):
+    # (... ; and with the start of the solves as k_cg_init_seg instead of on iteration 0's operator kernel)
+    for carry, lastblock, restart, init in (("1", "0", "1", "1"), ("0", "1", "1", "1"), ("0", "0", "1", "1"), ("1", "0", "0", "1"), ("1", "0", "1", "0"),
+                                            ("1", "0", "0", "0")):
         monkeypatch.setenv("LORADS_SEG_CARRY", carry)
         monkeypatch.setenv("LORADS_SEG_LASTBLOCK", lastblock)
         monkeypatch.setenv("LORADS_SEG_CARRY_RESTART", restart)
+        monkeypatch.setenv("LORADS_SEG_CARRY_INIT", init)
         params = dict(phase1Tol=1e-1) if tlr is None else dict(phase1Tol=1e-1, timesLogRank=tlr)
         s = common.hip_session(path, **params)
         try:
