@@ -248,6 +248,37 @@ def install_native_rccl(s, dist, torch, device, world, rank):
     return True
 
 
+def install_scalar_exchange(s, dist, torch, device, world, rank):
+    """Separable shards on the GPUs of one node: the four scalars of an ADMM iteration's evaluation go from host to host through a
+    page of shared memory (lorads_hip_set_scalar_exchange, csrc/host/shmx.c) -- no collective kernel between two iterations; the
+    all-reduce hook stays for phase 1 and for the m-vector form.  Checked before use (the ranks' numbers 1..N must sum to N(N+1)/2
+    on every rank); LORADS_SHM_EXCHANGE=0 keeps the collective.  Returns a word for the bench line."""
+    if not getattr(s, "separable", False) or world < 2 or os.environ.get("LORADS_SHM_EXCHANGE", "1") == "0":
+        return None
+    if int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world:     # ranks on several nodes: the collective
+        return None
+    box = [None]
+    if rank == 0:
+        box[0] = "/lorads_%d_%d_%x" % (os.getuid(), os.getpid(), int(time.time() * 1e3) & 0xffffff)
+    dist.broadcast_object_list(box, src=0)
+    ok = 1.0
+    try:
+        s.set_scalar_exchange_shm(box[0], world, rank)
+        got = s.shmx_allreduce([rank + 1.0, 1.0])
+        if got != [world * (world + 1) / 2.0, float(world)]:
+            ok = 0.0
+    except Exception as e:  # noqa: BLE001
+        log("rank %d: shared-memory scalar exchange not usable: %s" % (rank, e))
+        ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float64, device=device)    # all ranks take the same branch
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if t.item() != 1.0:
+        s.clear_scalar_exchange()
+        return None
+    log("rank %d: evaluation scalars of separable shards: host exchange through shared memory %s" % (rank, box[0]))
+    return "host shared memory"
+
+
 def install_allreduce(s, dist, torch, device, world, rank, backend):
     """Registers the hook; uses the stream-ordered form with RCCL after a self-check through the library
     (constrValSum filled with rank+1 must come back as world*(world+1)/2), else the synchronising form.
@@ -427,10 +458,11 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     t_setup1 = time.time()
     s.attach_hip()
     t_setup2 = time.time()
-    ar_mode, ranks_seen = None, 1
+    ar_mode, ranks_seen, sx_mode = None, 1, None
     if dist:
         ar_mode, ranks_seen = install_allreduce(s, dist, torch, device, world, rank, os.environ.get("LORADS_DIST_BACKEND", "nccl"))
         log("rank %d: all-reduce hook mode: %s, ranks seen through the library's hook: %d" % (rank, ar_mode, ranks_seen))
+        sx_mode = install_scalar_exchange(s, dist, torch, device, world, rank)
     be = s.be
     info = s.block_info(0)
     nloc = s.nblk
@@ -559,6 +591,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "ranks_seen": ranks_seen,
+            "scalar_exchange": sx_mode,
             "admm_iters_per_s_of_the_sharded_problem": a.steps / elapsed,
             "speculation_misses_in_timed_region": int(prof["speculation_misses"]),   # (solves resumed after a host round trip)
             "cg_iters_per_s": cg_iters / elapsed,

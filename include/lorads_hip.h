@@ -152,6 +152,16 @@ int lorads_hip_set_allreduce_stream_ordered(lorads_hip_ctx *ctx, int32_t on);
  * {||b - A(RR^T)||^2 part, b.lambda part, <C,RR^T> part, "my sweep is unfinished"}, and the rank's iteration is the
  * single-GPU iteration (all its fused paths) around it.  lorads_hip_get_vec / set_vec move the rank's own pieces. */
 int lorads_hip_set_separable(lorads_hip_ctx *ctx, int32_t on);
+/* Separable shards on the GPUs of ONE node: the four scalars of an ADMM iteration's evaluation are read by nobody but the ranks'
+ * hosts, which wait for their GPU's result hand-over at that very point.  With a scalar exchange installed the library takes the
+ * collective off the stream: the evaluation leaves the rank's LOCAL sums in the control block, the hand-over kernel delivers them
+ * with everything else, and each rank's host calls fn(user, vals, 4) -- which must leave in vals the sums over all ranks, the same
+ * bits on every rank -- before it looks at them (lorads_amd/csrc/host/shmx.c: a page of POSIX shared memory, sums in rank order).
+ * The sharded iteration's launch chain is then the single-GPU chain + one one-workgroup kernel.  Phase 1's collectives (which feed
+ * device-side consumers) and the m-vector form keep the all-reduce hook.  fn = NULL removes it.  (The reference has no counterpart:
+ * it sweeps all cones in one process, lorads_alg/lorads_alg_common.c:190-214.) */
+typedef int (*lorads_hip_scalar_exchange_fn)(void *user, double *vals, int32_t n);
+int lorads_hip_set_scalar_exchange(lorads_hip_ctx *ctx, lorads_hip_scalar_exchange_fn fn, void *user);
 /* all-reduces constrValSum through the hook once (lets the caller validate its hook) */
 int lorads_hip_selfcheck_allreduce(lorads_hip_ctx *ctx);
 

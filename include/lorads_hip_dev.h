@@ -53,6 +53,9 @@ int lorads_hip_graph_stats(lorads_hip_ctx *ctx, int64_t stats[4]);
  * table, data/lorads_sdp_conic.c:868-1076): stats = {sparsity patterns built by the device sorts, of these compared with the host
  * construction (LORADS_PRESOLVE_CHECK=1; a difference fails lorads_hip_create)} */
 int lorads_hip_presolve_stats(lorads_hip_ctx *ctx, int64_t stats[2]);
+/* evaluations of separable shards whose four scalars the ranks' hosts have summed (lorads_hip_set_scalar_exchange) instead of a
+ * collective on the stream */
+int lorads_hip_scalar_exchange_count(lorads_hip_ctx *ctx, int64_t *n);
 
 #ifdef __cplusplus
 }

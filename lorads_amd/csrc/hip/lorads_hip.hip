@@ -76,6 +76,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int MINPART = 4096; // least capacity of one partial-sum slot; a context sizes its slots to its largest cone (lorads_hip_ctx::maxpart)
+constexpr int SX_WORD = 56; // control-block words [56, 60): a rank's local sums of an evaluation on their way to its host (lorads_hip_set_scalar_exchange)
 constexpr int NSLOT = 20; // (18, 19: start-of-solve and restart residual partials of the ADMM sweep, see solve_front)
 
 thread_local std::string g_err;
@@ -567,6 +568,12 @@ struct lorads_hip_ctx {
                         bool ride_res = false; } pend_segchk; // ride_res: the restart's residual pass that follows may take it (see op_diag)
     struct PendSegInit { bool on = false; int half = 0; double tol = 0; Guard front{}; const double *part_rr = nullptr, *part_b = nullptr; } pend_seginit; // lockstep sweep: the solves' start waiting for iteration 0's operator kernel
     bool opt_seg_carry_init = true; // (LORADS_SEG_CARRY_INIT=0: k_cg_init_seg as a launch of its own)
+    // separable shards: the evaluation's four scalars summed by the ranks' hosts after the hand-over (lorads_hip_set_scalar_exchange)
+    lorads_hip_scalar_exchange_fn sx = nullptr;
+    void *sx_user = nullptr;
+    bool sx_pending = false; // the local sums are on their way to the mirror (scal[SX_WORD..+4)); the next wait_publish exchanges them
+    int sx_with_obj = 0;
+    long long n_sx = 0;
     bool opt_seg_carry_restart = true; // lockstep sweep: the k % 20 == 0 restart's test and scalars ride on its two operator kernels (LORADS_SEG_CARRY_RESTART=0)
     double *seg_rr_alt = nullptr; // second slot of every stage's r.r (see SegArgs)
     int *seg_tile_info = nullptr; // int4 per row tile of the merged cone (see DirArgs.seg_info)
@@ -776,6 +783,14 @@ int lorads_hip_set_allreduce(lorads_hip_ctx *c, lorads_hip_allreduce_fn fn, void
     return 0;
 }
 
+int lorads_hip_set_scalar_exchange(lorads_hip_ctx *c, lorads_hip_scalar_exchange_fn fn, void *user) {
+    if (!c) return fail_msg("set_scalar_exchange: no context");
+    if (c->sx_pending || c->sep_pending) { // (an evaluation's sums are still on their way: finish that hand-over under the old rule first)
+        if (read_states(c)) return 1;
+    }
+    c->sx = fn; c->sx_user = user;
+    return 0;
+}
 int lorads_hip_set_separable(lorads_hip_ctx *c, int32_t on) {
     flush_pending(c);
     c->sep = on != 0;
@@ -1409,6 +1424,11 @@ int lorads_hip_block_image(lorads_hip_ctx *c, int32_t k, int64_t im[16]) {
     const int64_t v[16] = {B.n, B.r, B.nrow, B.na, B.nc, B.pa.ne, B.pu.ne, B.dense_c, B.dense_a ? B.nd : 0, B.diag_only, B.entry_only,
                            B.use_cw, B.has_gram, B.front_cw, B.cell_w, B.bip_n[0]};
     for (int i = 0; i < 16; ++i) im[i] = v[i];
+    return 0;
+}
+
+int lorads_hip_scalar_exchange_count(lorads_hip_ctx *c, int64_t *n) {
+    *n = c->n_sx;
     return 0;
 }
 

@@ -208,6 +208,15 @@ int lrd_parse_entry_line(const char *line, int ij[4], double *val);
 uint64_t lrd_problem_digest(const lrd_problem *p);
 /* 1 when the start point is drawn by the inline copy of glibc's rand() recurrence (verified against rand() at run time), 0 when by rand() */
 int lrd_start_generator_is_inline(void);
+
+/* ---- shmx.c: sums of a few doubles (n <= 16) over the ranks of one node through POSIX shared memory; the scalar exchange of
+ * separable shards (include/lorads_hip.h: lorads_hip_set_scalar_exchange).  name: "/..." -- the same on every rank, unique per run;
+ * rank 0 creates and removes the segment.  All return 0 on success. */
+typedef struct lrd_shmx lrd_shmx;
+int lrd_shmx_open(const char *name, int world, int rank, lrd_shmx **out);
+int lrd_shmx_allreduce(lrd_shmx *x, double *v, int n);
+int lrd_shmx_hook(void *user, double *vals, int32_t n);
+void lrd_shmx_close(lrd_shmx *x);
 /* Build a problem from arrays (bench / tests; 0-based mat: 0 = F0, blk, row, col); same
  * post-processing as the reader (F0 negated, lower triangle, tiny entries dropped, pre-solve). */
 int lrd_problem_from_triplets(int m, const double *b, int nblk, const int *dims, int64_t nent, const int *e_mat,

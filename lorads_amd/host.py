@@ -504,6 +504,38 @@ class Session:
         self.lib.lrd_session_set_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _check(self.lib.lrd_session_set_allreduce(self.h, fn_ptr, C.c_void_p(user)), "set_allreduce")
 
+    def set_scalar_exchange_shm(self, name, world, rank):
+        """Separable shards on one node: the evaluation's four scalars are summed by the ranks' hosts through a page of POSIX shared
+        memory (csrc/host/shmx.c) instead of a collective on the stream (lorads_hip_set_scalar_exchange).  name: '/...', the same on
+        every rank and unique per run.  Returns the exchange's handle (closed by close())."""
+        lib, ctx = self._hip()
+        h = C.c_void_p()
+        self.lib.lrd_shmx_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.lib.lrd_shmx_open(name.encode(), int(world), int(rank), C.byref(h)), "shmx_open")
+        lib.lorads_hip_set_scalar_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib.lorads_hip_set_scalar_exchange(ctx, C.cast(self.lib.lrd_shmx_hook, C.c_void_p), h), "set_scalar_exchange")
+        self._shmx = h
+        return h
+
+    def hip_scalar_exchange_count(self):
+        lib, ctx = self._hip()
+        n = C.c_int64()
+        lib.lorads_hip_scalar_exchange_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_scalar_exchange_count(ctx, C.byref(n)), "scalar_exchange_count")
+        return int(n.value)
+
+    def clear_scalar_exchange(self):
+        lib, ctx = self._hip()
+        lib.lorads_hip_set_scalar_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib.lorads_hip_set_scalar_exchange(ctx, None, None), "set_scalar_exchange")
+
+    def shmx_allreduce(self, values):
+        """sums `values` (<= 16 doubles) over the ranks through the exchange opened by set_scalar_exchange_shm (tests, agreement steps)"""
+        v = (C.c_double * len(values))(*values)
+        self.lib.lrd_shmx_allreduce.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        _check(self.lib.lrd_shmx_allreduce(self._shmx, v, len(values)), "shmx_allreduce")
+        return list(v)
+
     def use_fused_step(self, on):
         self.lib.lrd_session_use_fused_step.argtypes = [C.c_void_p, C.c_int]
         _check(self.lib.lrd_session_use_fused_step(self.h, int(on)), "use_fused_step")
@@ -547,6 +579,10 @@ class Session:
         if self.h:
             self.lib.lrd_session_close(self.h)
             self.h = None
+        if getattr(self, "_shmx", None):
+            self.lib.lrd_shmx_close.argtypes = [C.c_void_p]
+            self.lib.lrd_shmx_close(self._shmx)
+            self._shmx = None
 
     def __enter__(self):
         return self

@@ -21,5 +21,7 @@ cp $O/bench_cfg4_1gpu.json profiles/r03_bench_cfg4_blk16x4000_1gpu.json
 cp $O/bench_cfg2_maxcut800.json profiles/r03_bench_cfg2_maxcut800.json
 cp $O/rehearsal_gpus2_weak_gloo_one_card.json profiles/r03_rehearsal_gpus2_weak_gloo_one_card.json
 cp $O/rehearsal_gpus4_strong_gloo_one_card.json profiles/r03_rehearsal_gpus4_strong_blk16x4000_gloo_one_card.json
+cp $O/rehearsal_gpus2_weak_gloo_one_card_hook.json profiles/r03_rehearsal_gpus2_weak_gloo_one_card_hook.json
+cp $O/rehearsal_gpus4_strong_gloo_one_card_hook.json profiles/r03_rehearsal_gpus4_strong_blk16x4000_gloo_one_card_hook.json
 cp $O/r03_stamp.json profiles/r03_stamp.json
 python profiles/tools/stamp.py r03

@@ -9,8 +9,12 @@ bench)
   python bench.py --workload matcomp50000 --steps 40 --warmup 4 --cpu-budget 30 > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 rc=$?"
   python bench.py --workload blk16x4000 --times-log-rank 2.0 --steps 100 --warmup 5 > $O/bench_cfg4_1gpu.json 2> $O/bench_cfg4_1gpu.err; echo "cfg4 rc=$?"
   python bench.py --workload maxcut800 --times-log-rank 2.0 --steps 200 --warmup 10 --no-extra > $O/bench_cfg2_maxcut800.json 2> $O/bench_cfg2.err; echo "cfg2 rc=$?"
+  # one-card rehearsals of the sharded bench (gloo hook, N processes on the one GPU): the evaluation's scalars from host to host through
+  # shared memory (the default on one node) and, _hook, through the all-reduce hook (LORADS_SHM_EXCHANGE=0)
   LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus2_weak_gloo_one_card.json 2> $O/rehearsal_gpus2.err; echo "gpus2 rc=$?"
   LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 4 --scaling strong --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus4_strong_gloo_one_card.json 2> $O/rehearsal_gpus4.err; echo "gpus4 rc=$?"
+  LORADS_SHM_EXCHANGE=0 LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus2_weak_gloo_one_card_hook.json 2> $O/rehearsal_gpus2_hook.err; echo "gpus2 hook rc=$?"
+  LORADS_SHM_EXCHANGE=0 LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 python bench.py --gpus 4 --scaling strong --steps 50 --warmup 5 --no-cpu > $O/rehearsal_gpus4_strong_gloo_one_card_hook.json 2> $O/rehearsal_gpus4_hook.err; echo "gpus4 hook rc=$?"
   python profiles/tools/ubench.py 200 1,2,30,31,32,8,10,23,24 > $O/ubench.txt 2> $O/ubench.err
   python profiles/tools/size_sweep.py 200 > $O/size_sweep.txt 2> $O/size_sweep.err
   python profiles/tools/stamp.py r03 $O

@@ -34,9 +34,12 @@ def _worker(rank, world, port, name, params, q):
     try:
         mode, seen = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
         assert seen == world, ("ranks seen by the library's own hook", seen, world)
+        if os.environ.get("LORADS_TEST_SHMX"):   # the evaluation's scalars from host to host (lorads_hip_set_scalar_exchange)
+            s.set_scalar_exchange_shm(os.environ["LORADS_TEST_SHMX"], world, rank)
         s.hip_profile(1, 1 << 30)   # (counts the solves resumed after a missed speculation)
         s.solve()
         r = s.results()
+        r["exchanges"] = s.hip_scalar_exchange_count()
         r["speculation_misses"] = int(s.hip_profile_read()["speculation_misses"])
         r["nblk_local"] = s.nblk
         r["mode"] = mode
@@ -66,7 +69,13 @@ def _worker(rank, world, port, name, params, q):
     # speculation window 1 (enqueue what the previous sweep needed): a miss every other iteration -- the "somebody missed, everybody
     # evaluates again" protocol of both forms at work (the default window's runs above already miss at different iterations per rank)
     ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, True),
-    ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False)])
+    ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, False),
+    # the separable form with the evaluation's four scalars summed by the ranks' HOSTS through shared memory (no collective on the
+    # stream in phase 2): whole solves with reopt rounds and rank growth, one cone per rank, and the miss protocol at work
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 2, "shm"),
+    ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, "shm"),
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), 4, "shm"),
+    ("mix4+misses", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), 2, "shm")])
 def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, params, world, separable):
     """Sharded cones, one process per rank on the card.  separable=True: no constraint touches cones of two ranks, each rank works
     on the sub-problem over its own constraints and the ranks share scalars only (lorads_hip_set_separable: four doubles per ADMM
@@ -74,6 +83,12 @@ def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, para
     from tests import common
     provoke = name.endswith("+misses")
     name = name.split("+")[0]
+    shm = separable == "shm"
+    separable = bool(separable)
+    if shm:
+        monkeypatch.setenv("LORADS_TEST_SHMX", "/lorads_test_%d_%s_%d" % (os.getpid(), name, world))
+    else:
+        monkeypatch.delenv("LORADS_TEST_SHMX", raising=False)
     with common.hip_session(common.instance_path(name), **params) as s:
         s.solve()
         ref = s.results()
@@ -97,6 +112,10 @@ def test_two_ranks_on_device_match_single_process(built, monkeypatch, name, para
             if p.is_alive():
                 p.kill()
     a = out[0]
+    if shm:     # phase 2's evaluations went from host to host (phase 1's collectives keep the hook)
+        assert all(out[r]["exchanges"] >= a["admm_iter"] > 0 for r in range(world)), [out[r]["exchanges"] for r in range(world)]
+    else:
+        assert all(out[r]["exchanges"] == 0 for r in range(world))
     assert sum(out[r]["nblk_local"] for r in range(world)) == nb_all
     assert all(out[r]["separable"] == separable for r in range(world))
     if separable:
@@ -141,7 +160,7 @@ def test_native_rccl_hook_whole_solves_on_one_rank(built):
     assert sum(" separable " in ln for ln in lines) == 4
 
 
-def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q):
+def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q, shm=None):
     """one rank of test_fullsize_sharded_iterations...: the cones dealt to it, the single-process state loaded into them, `its`
     ADMM iterations with the cross-rank sums through the device-buffer all-reduce hook"""
     sys.path.insert(0, ROOT)
@@ -160,6 +179,8 @@ def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q)
     try:
         mode, seen = bench.install_allreduce(s, dist, torch, device, world, rank, "gloo")
         assert seen == world
+        if shm:      # the evaluation's scalars from host to host through shared memory instead of through the hook
+            s.set_scalar_exchange_shm(shm, world, rank)
         st = np.load(statefile)
         for j in range(s.nblk):                 # cones are dealt round robin: local cone j is cone rank + j * world of the file
             k = rank + j * world
@@ -175,7 +196,7 @@ def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q)
         s.hip_sync()
         Us = {"U%d" % (rank + j * world): be.get_mat(host.MAT_U, j) for j in range(s.nblk)}
         q.put((rank, dict(err0=e0, err1=e1, cg=int(cg), pObj=p1, dObj=d1, nblk_local=s.nblk, m_local=s.m, separable=bool(s.separable),
-                          mode=mode, U=Us)))
+                          mode=mode, U=Us, exchanges=s.hip_scalar_exchange_count())))
     finally:
         s.close()
         dist.barrier()
@@ -183,7 +204,7 @@ def _worker_fullsize(rank, world, port, path, tlr, statefile, its, separable, q)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,separable", [(2, True), (4, True), (2, False), (4, False)])
+@pytest.mark.parametrize("world,separable", [(2, True), (4, True), (2, False), (4, False), (2, "shm"), (4, "shm")])
 def test_fullsize_sharded_iterations_match_one_process_and_the_reference(built, world, separable):
     """BASELINE cfg4 at full size -- 16 cones of n = 4000, 64000 constraints -- dealt over 2 and 4 ranks (processes on the one card,
     device-buffer all-reduce hook), in the scalars-only form of separable shards and in the m-vector form: 20 ADMM iterations from
@@ -197,6 +218,10 @@ def test_fullsize_sharded_iterations_match_one_process_and_the_reference(built, 
     from lorads_amd import host
     from tests import common
     from tests.test_hip_parity import _gen
+    # "shm": the separable form with the evaluation's four scalars summed by the ranks' hosts through shared memory
+    # (lorads_hip_set_scalar_exchange) -- no collective on the stream between two ADMM iterations
+    shm = "/lorads_test_%d_%d" % (os.getpid(), world) if separable == "shm" else None
+    separable = bool(separable)
     its, tlr = 20, 2.0
     path = _gen("blk16x4000")
     statefile = "/tmp/lorads_shard_state_%d.npz" % os.getpid()
@@ -240,7 +265,7 @@ def test_fullsize_sharded_iterations_match_one_process_and_the_reference(built, 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_fullsize, args=(r, world, port, path, tlr, statefile, its, separable, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_fullsize, args=(r, world, port, path, tlr, statefile, its, separable, q, shm)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -256,6 +281,10 @@ def test_fullsize_sharded_iterations_match_one_process_and_the_reference(built, 
             if os.path.exists(f):
                 os.remove(f)
     a = out[0]
+    if shm:     # every evaluation of the 20 iterations (and the two in front of them) went from host to host
+        assert all(out[r]["exchanges"] >= its for r in range(world)), [out[r]["exchanges"] for r in range(world)]
+    else:
+        assert all(out[r]["exchanges"] == 0 for r in range(world))
     assert sum(out[r]["nblk_local"] for r in range(world)) == nb
     assert all(out[r]["separable"] == separable for r in range(world))
     for r in range(1, world):   # every rank holds the same summed scalars
