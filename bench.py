@@ -257,25 +257,44 @@ def install_scalar_exchange(s, dist, torch, device, world, rank):
         return None
     if int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world:     # ranks on several nodes: the collective
         return None
-    box = [None]
-    if rank == 0:
-        box[0] = "/lorads_%d_%d_%x" % (os.getuid(), os.getpid(), int(time.time() * 1e3) & 0xffffff)
-    dist.broadcast_object_list(box, src=0)
+    # the segment's name: the same on every rank without a message (the rendezvous port is this run's own); rank 0 makes the segment
+    # -- a leftover of that name goes first -- BEFORE the others open it
+    name = "/lorads_%d_%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0"))
     ok = 1.0
     try:
-        s.set_scalar_exchange_shm(box[0], world, rank)
-        got = s.shmx_allreduce([rank + 1.0, 1.0])
-        if got != [world * (world + 1) / 2.0, float(world)]:
-            ok = 0.0
+        if rank == 0:
+            s.set_scalar_exchange_shm(name, world, rank)
     except Exception as e:  # noqa: BLE001
         log("rank %d: shared-memory scalar exchange not usable: %s" % (rank, e))
+        ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float64, device=device)    # (doubles as the barrier between rank 0's create and the others' open)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if t.item() != 1.0:
+        return None
+    try:
+        if rank != 0:
+            s.set_scalar_exchange_shm(name, world, rank)
+    except Exception as e:  # noqa: BLE001
+        log("rank %d: shared-memory scalar exchange not usable: %s" % (rank, e))
+        ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if t.item() == 1.0:      # every rank is attached: the ranks' numbers 1..N must sum to N(N+1)/2 on every rank
+        try:
+            got = s.shmx_allreduce([rank + 1.0, 1.0])
+            if got != [world * (world + 1) / 2.0, float(world)]:
+                ok = 0.0
+        except Exception as e:  # noqa: BLE001
+            log("rank %d: shared-memory scalar exchange failed its check: %s" % (rank, e))
+            ok = 0.0
+    else:
         ok = 0.0
     t = torch.tensor([ok], dtype=torch.float64, device=device)    # all ranks take the same branch
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if t.item() != 1.0:
         s.clear_scalar_exchange()
         return None
-    log("rank %d: evaluation scalars of separable shards: host exchange through shared memory %s" % (rank, box[0]))
+    log("rank %d: evaluation scalars of separable shards: host exchange through shared memory %s" % (rank, name))
     return "host shared memory"
 
 
