@@ -105,6 +105,10 @@ def test_device_sorts_build_the_host_patterns_small(built, case, monkeypatch):
     try:
         st = s.hip_presolve_stats()
         assert st["device"] >= 2 and st["checked"] == st["device"], st      # (A-pattern and union pattern of every cone)
+        # ... and nothing the construction launched was refused (an empty pattern must not become an empty grid): the next result
+        # hand-over looks at the runtime's last error
+        s.be.init_constr(host.PAIR_UV)
+        assert np.isfinite(s.be.update_dimacs(host.PAIR_UV))
     finally:
         s.close()
 
