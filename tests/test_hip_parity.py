@@ -910,6 +910,40 @@ def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_laun
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name", ["blk4x60", "mix4"])
+def test_lockstep_carriers_at_iteration_limits_and_later_restarts(built, monkeypatch, name):
+    """The lockstep sweep's carried scalar steps where the plain runs of the test above do not go: iteration limits of 1, 2 and 3 (the
+    solves' start rides on the only operator kernel there is; the k = 0 restart is the last thing a solve does), and solves that run
+    to a limit of 45 at a tolerance nobody reaches -- the restarts at k = 20 and k = 40 then find a convergence test waiting and take
+    it along on their residual pass.  Carried (default) against every scalar step as a launch of its own: bit for bit."""
+    path = common.instance_path(name)
+    res = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("LORADS_SEG_CARRY", carry)
+        s = common.hip_session(path, phase1Tol=1e-1)
+        try:
+            s.alm()
+            s.alm_to_admm()
+            r0 = s.results()
+            rho = min(r0["admm_rho"] if r0["admm_rho"] > 0 else r0["alm_rho"], 5000.0)
+            s.be.init_constr(host.PAIR_UV)
+            log = []
+            for tol, maxit in ((1e-6, 1), (1e-6, 2), (1e-9, 3), (1e-30, 45), (1e-30, 45), (1e-6, 1), (1e-30, 21), (1e-8, 300)):
+                c, p_, d, e = s.be.admm_step(rho, tol, maxit)
+                s.be.update_dual_var(rho)
+                log.append((c, p_, d, e))
+            res.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)], [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)]))
+        finally:
+            s.close()
+    (la, Ua, Va), (lb, Ub, Vb) = res
+    print(name, "CG iterations per step", [c for c, _, _, _ in la])
+    nb = len(Ua)
+    assert la[0][0] == 2 * nb and la[3][0] == 2 * 45 * nb and la[6][0] == 2 * 21 * nb      # (every solve ran to its limit)
+    assert la == lb, (la, lb)
+    for x, y in zip(Ua + Va, Ub + Vb):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("name,tlr", [("matcomp60", None), ("matcomp4000", 3.0)])
 def test_bipartite_entry_operator_equals_the_one_kernel_form(built, monkeypatch, name, tlr):
     """Single-entry cones whose entry graph is bipartite (matrix completion): k_op_entry_bip forms every entry's pair dot once, on
