@@ -11,6 +11,8 @@ cp $O/rand20000_general_form_admm_part_summary.txt profiles/r03_rand20000_genera
 cp $O/rand20000_general_form_kernel_stats.csv profiles/r03_general_form_rand20000_kernel_stats.csv
 cp $O/pmc_rand20000.json profiles/r03_pmc_rand20000.json
 cp $O/pmc_maxcut20000.json profiles/r03_pmc_maxcut20000.json
+[ -f $O/pmc_blk16x4000.json ] && cp $O/pmc_blk16x4000.json profiles/r03_pmc_blk16x4000.json
+[ -f $O/pmc_matcomp50000.json ] && cp $O/pmc_matcomp50000.json profiles/r03_pmc_matcomp50000.json
 cp $O/pmc_rand20000_general_form.json profiles/r03_pmc_rand20000_general_form.json
 cp $O/l2_hit_rate_rand20000.json profiles/r03_l2_hit_rate_rand20000.json
 cp $O/ubench.txt profiles/r03_ubench.txt

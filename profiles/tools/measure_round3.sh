@@ -35,9 +35,10 @@ prof)
   python profiles/tools/stamp.py r03 $O
   ;;
 pmc)
-  for w in rand20000 maxcut20000; do
+  for w in ${PMC_WORKLOADS:-rand20000 maxcut20000 blk16x4000 matcomp50000}; do
+    TL=4.0; [ $w = matcomp50000 ] && TL=5.5; [ $w = blk16x4000 ] && TL=2.0
     for cn in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $cn --output-format csv -d $O/p_${cn}_$w -o p -- python3 bench.py $B --workload $w --steps 6 --warmup 2 > $O/p_${cn}_$w.log 2>&1
+      rocprofv3 --pmc $cn --output-format csv -d $O/p_${cn}_$w -o p -- python3 bench.py $B --workload $w --times-log-rank $TL --steps 6 --warmup 2 > $O/p_${cn}_$w.log 2>&1
     done
     python profiles/pmc_summary.py $(ls $O/p_FETCH_SIZE_$w/*counter_collection.csv | head -1) $(ls $O/p_WRITE_SIZE_$w/*counter_collection.csv | head -1) $O/pmc_$w.json $w
     rm -f $O/p_FETCH_SIZE_$w/*counter_collection.csv $O/p_WRITE_SIZE_$w/*counter_collection.csv
