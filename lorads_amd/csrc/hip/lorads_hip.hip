@@ -329,7 +329,7 @@ __device__ __forceinline__ int run_init(const InitArgs &ia, const Guard &g, doub
     return conv ? 2 : 0;
 }
 
-enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3, W_ADMM_V = 4 };
+enum { W_COMPACT = 0, W_ADMM = 1, W_ALM = 2, W_DUAL = 3, W_ADMM_V = 4, W_ADMM_VS = 5 }; // (VS: as V, the row dot formed by the front itself, see k_spmm2)
 enum { OP_CG = 0, OP_RES = 1, OP_RHS = 2, OP_GRAD = 3 };
 enum { CHK_ITER = 1, CHK_RESTART = 2 };
 enum { DIR_BETA = 1, DIR_RESTART = 2 };
@@ -574,6 +574,7 @@ struct lorads_hip_ctx {
     bool sx_pending = false; // the local sums are on their way to the mirror (scal[SX_WORD..+4)); the next wait_publish exchanges them
     int sx_with_obj = 0;
     long long n_sx = 0;
+    bool opt_seg_virt = true; // lockstep sweep, Max-Cut-type merged cone, evaluation at the end: the refresh after the U-solves is not stored, the V front forms its weights from U_p.V_p itself (LORADS_SEG_VIRT=0: k_pairdots + k_cv)
     bool opt_seg_carry_restart = true; // lockstep sweep: the k % 20 == 0 restart's test and scalars ride on its two operator kernels (LORADS_SEG_CARRY_RESTART=0)
     double *seg_rr_alt = nullptr; // second slot of every stage's r.r (see SegArgs)
     int *seg_tile_info = nullptr; // int4 per row tile of the merged cone (see DirArgs.seg_info)
@@ -706,6 +707,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
     c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
     c->opt_seg_carry_init = !(getenv("LORADS_SEG_CARRY_INIT") && getenv("LORADS_SEG_CARRY_INIT")[0] == '0');
+    c->opt_seg_virt = !(getenv("LORADS_SEG_VIRT") && getenv("LORADS_SEG_VIRT")[0] == '0');
     c->opt_seg_carry_restart = !(getenv("LORADS_SEG_CARRY_RESTART") && getenv("LORADS_SEG_CARRY_RESTART")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
