@@ -575,6 +575,7 @@ struct lorads_hip_ctx {
     int sx_with_obj = 0;
     long long n_sx = 0;
     bool opt_seg_virt = true; // lockstep sweep, Max-Cut-type merged cone, evaluation at the end: the refresh after the U-solves is not stored, the V front forms its weights from U_p.V_p itself (LORADS_SEG_VIRT=0: k_pairdots + k_cv)
+    bool opt_seg_carry_dual = true; // lockstep sweep: a waiting dual update rides on the U front of the merged cone (LORADS_SEG_CARRY_DUAL=0: k_dual_update)
     bool opt_seg_carry_restart = true; // lockstep sweep: the k % 20 == 0 restart's test and scalars ride on its two operator kernels (LORADS_SEG_CARRY_RESTART=0)
     double *seg_rr_alt = nullptr; // second slot of every stage's r.r (see SegArgs)
     int *seg_tile_info = nullptr; // int4 per row tile of the merged cone (see DirArgs.seg_info)
@@ -708,6 +709,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
     c->opt_seg_carry_init = !(getenv("LORADS_SEG_CARRY_INIT") && getenv("LORADS_SEG_CARRY_INIT")[0] == '0');
     c->opt_seg_virt = !(getenv("LORADS_SEG_VIRT") && getenv("LORADS_SEG_VIRT")[0] == '0');
+    c->opt_seg_carry_dual = !(getenv("LORADS_SEG_CARRY_DUAL") && getenv("LORADS_SEG_CARRY_DUAL")[0] == '0');
     c->opt_seg_carry_restart = !(getenv("LORADS_SEG_CARRY_RESTART") && getenv("LORADS_SEG_CARRY_RESTART")[0] == '0');
     c->opt_cw_quad = !(getenv("LORADS_CW_QUAD") && getenv("LORADS_CW_QUAD")[0] == '0');
     c->opt_front_cw = !(getenv("LORADS_FRONT_CW") && getenv("LORADS_FRONT_CW")[0] == '0');
@@ -1185,7 +1187,10 @@ int lorads_hip_admm_step(lorads_hip_ctx *c, double rho, double tol, int32_t maxi
 int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
     c->ls_np = 0;
     // (see pend_dual; with sharded cones only the one-kernel front can take it: it needs no owner pairs, k_wsum stores all of lambda)
-    if (c->opt_lazy_scalars && c->lambda_alt && c->nb == 1 && (!shard_vec(c) || front_cw_ok(c, c->blk[0]))) {
+    // (lockstep sweep of a Max-Cut-type merged cone that sees every constraint: its U front takes it, see enqueue_batched)
+    const bool merged_front = c->has_merged && c->opt_seg_carry_dual && c->merged.diag_only && c->merged.rc_w > 0 && c->merged.w_uv &&
+                              c->merged.nrow == c->m && c->opt_front_diag && !c->opt_split_front && !shard_vec(c) && !getenv("LORADS_NO_BATCH");
+    if (c->opt_lazy_scalars && c->lambda_alt && ((c->nb == 1 && (!shard_vec(c) || front_cw_ok(c, c->blk[0]))) || merged_front)) {
         flush_pending(c);
         c->pend_dual = true;
         c->pend_dual_rho = rho;

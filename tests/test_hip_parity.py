@@ -884,6 +884,7 @@ def test_lockstep_convergence_test_on_the_last_workgroup_is_bitwise_its_own_laun
         # (the last variant also stores the refresh after the U-solves -- k_pairdots + k_cv -- instead of letting the V front form its
         # weights from U_p . V_p itself)
         monkeypatch.setenv("LORADS_SEG_VIRT", "0" if (restart, init) == ("0", "0") else "1")
+        monkeypatch.setenv("LORADS_SEG_CARRY_DUAL", "0" if (restart, init) == ("0", "0") else "1")      # (... and the dual update as k_dual_update)
         monkeypatch.setenv("LORADS_SEG_CARRY", carry)
         monkeypatch.setenv("LORADS_SEG_LASTBLOCK", lastblock)
         monkeypatch.setenv("LORADS_SEG_CARRY_RESTART", restart)
