@@ -486,6 +486,12 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     info = s.block_info(0)
     nloc = s.nblk
     # ---- untimed set-up: phase 1 on the GPU gives the factors, then the hand-off
+    # (the counting window is opened in front of phase 1: opening it creates the event pool, tens of milliseconds in which the GPU idles
+    # and clocks down -- between phase 1 and the warm-up that idle time showed in the first timed steps; the timed region's counts are
+    # differences of two reads.  With --sample-every the window opens after phase 1, whose applications would use up the pool.)
+    prof_early = a.sample_every <= 0
+    if prof_early:
+        s.hip_profile(1, 1 << 30)
     t0 = time.time()
     s.alm()
     s.alm_to_admm()
@@ -503,10 +509,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     # fetching the factors and writing them out idles the GPU for tens of milliseconds, and taken here -- right in front of the warm-up
     # -- that idle time showed in the timed steps as a clock ramp: 0.127 against 0.124 ms per step)
 
-    # ---- warm-up, then exactly K timed steps.  The counting window is opened BEFORE the warm-up (opening it creates the event pool:
-    # tens of milliseconds in which the GPU idles and clocks down -- right in front of the timed region, the first timed steps paid
-    # for the ramp-up); the timed region's counts are differences of two reads.
-    s.hip_profile(1, a.sample_every if a.sample_every > 0 else 1 << 30)   # (counts applications either way)
+    # ---- warm-up, then exactly K timed steps
+    if not prof_early:
+        s.hip_profile(1, a.sample_every if a.sample_every > 0 else 1 << 30)
     err1, _, _, _ = admm_steps(be, host, rho, err1, a.warmup, s)
     prof0 = s.hip_profile_read()
     n_samp0 = len(s.hip_profile_samples())
