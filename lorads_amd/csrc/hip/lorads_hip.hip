@@ -376,6 +376,11 @@ struct Pattern {              // one symmetric sparsity pattern with everything 
 
 struct Block {
     int n = 0, r = 0, nrow = 0, na = 0, nc = 0;
+    // r is the rank the kernels see: the cone's rank rl rounded up to even (dev_rank), the extra column zero in every factor.  A zero
+    // column stays zero through every step of both phases (each column of S V, of the operator's result, of a gradient or direction is
+    // built from the same column of its input), and every even rank takes the 16-byte row accesses and the kernels that need them
+    // (k_front_cw, the quad form of k_cw): r = 41 ran at 0.175 ms per headline iteration, r = 42 at 0.131.
+    int rl = 0;
     size_t off = 0;           // offset of this cone in the flat factor arrays
     int *row_idx = nullptr;
     bool row_idx_identity = false; // row_idx[i] == i for every local constraint (a cone that sees all constraints in order)
@@ -533,6 +538,7 @@ struct lorads_hip_ctx {
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
     bool opt_dense_rem = true; // dense GEMM: 1..4 columns beyond the full tiles on plain FMAs instead of a tile of their own (LORADS_DENSE_REM=0)
+    bool opt_pad_rank = true; // odd ranks run as the next even rank with a zero column (LORADS_PAD_ODD_RANK=0: as they are)
     bool opt_dev_presolve = true;   // pattern work of the pre-solve on the device (presolve.inc; LORADS_DEV_PRESOLVE=0: host)
     bool opt_presolve_check = false; // LORADS_PRESOLVE_CHECK=1: build every device pattern on the host too and compare
     size_t dev_presolve_min = (size_t)1 << 15; // stored entries below which a pattern is built on the host (LORADS_DEV_PRESOLVE_MIN)
@@ -637,6 +643,8 @@ double *part_slot(lorads_hip_ctx *c, int k) { return c->part + (size_t)k * c->ma
 // sharded cones that share constraints: constrValSum, q1, q2 are summed over the ranks as m-vectors.  Separable shards
 // (lorads_hip_set_separable) hold their own constraints: only scalars are summed (c->ar && c->sep).
 inline bool shard_vec(const lorads_hip_ctx *c) { return c->ar && !c->sep; }
+// the rank the kernels run at (see Block::rl): odd ranks take a zero column along; the LP block's "rank" 1 is not a factor width
+inline int dev_rank(const lorads_hip_ctx *c, int r, bool is_lp) { return (c->opt_pad_rank && !is_lp && (r & 1) && r < 512) ? r + 1 : r; }
 
 #include "build.inc"
 #include "sweep.inc"
@@ -668,6 +676,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
         if (need > ((size_t)1 << 27)) { delete c; return fail_msg("cone dimension beyond 2^29 rows"); }
         c->maxpart = (int)std::max<size_t>((size_t)MINPART, (need + 255) & ~(size_t)255);
     }
+    c->opt_pad_rank = !(getenv("LORADS_PAD_ODD_RANK") && getenv("LORADS_PAD_ODD_RANK")[0] == '0');
     c->opt_dev_presolve = !(getenv("LORADS_DEV_PRESOLVE") && getenv("LORADS_DEV_PRESOLVE")[0] == '0');
     c->opt_presolve_check = getenv("LORADS_PRESOLVE_CHECK") && getenv("LORADS_PRESOLVE_CHECK")[0] == '1';
     if (getenv("LORADS_DEV_PRESOLVE_MIN")) c->dev_presolve_min = (size_t)std::max(0ll, atoll(getenv("LORADS_DEV_PRESOLVE_MIN")));
@@ -1255,8 +1264,8 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
     B.t_uv_valid = false;
     B.wj_for = nullptr;
     c->merged.t_uv_valid = false; // (its pair values of (U, V) cover this cone too)
-    std::vector<double> rm((size_t)B.n * B.r);
-    for (int j = 0; j < B.r; ++j)
+    std::vector<double> rm((size_t)B.n * B.r); // (zero-initialised: the padding column of an odd rank)
+    for (int j = 0; j < B.rl; ++j)
         for (int i = 0; i < B.n; ++i) rm[(size_t)i * B.r + j] = cm[(size_t)j * B.n + i];
     HC(hipMemcpyAsync(base + B.off, rm.data(), sizeof(double) * rm.size(), hipMemcpyHostToDevice, c->stream));
     HC(hipStreamSynchronize(c->stream));
@@ -1271,7 +1280,7 @@ int lorads_hip_get_mat(lorads_hip_ctx *c, int32_t which, int32_t k, double *cm) 
     std::vector<double> rm((size_t)B.n * B.r);
     HC(hipMemcpyAsync(rm.data(), base + B.off, sizeof(double) * rm.size(), hipMemcpyDeviceToHost, c->stream));
     HC(hipStreamSynchronize(c->stream));
-    for (int j = 0; j < B.r; ++j)
+    for (int j = 0; j < B.rl; ++j)
         for (int i = 0; i < B.n; ++i) cm[(size_t)j * B.n + i] = rm[(size_t)i * B.r + j];
     return 0;
 }
@@ -1303,31 +1312,32 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
     // arrays are released -- no copy through the host, no transposition (the device layout is row-major on both sides).
     for (int k = 0; k < c->nb; ++k) { // (refuse before anything is touched: a refused call leaves host and device at the old ranks)
         const Block &B = c->blk[k];
-        if (nr[k] < B.r || nr[k] > 512) return fail_msg("resize_rank: bad rank");
-        if (B.dense_c && nr[k] > 128 && B.ksplit_b == 0)
+        if (nr[k] < B.rl || nr[k] > 512) return fail_msg("resize_rank: bad rank");
+        const int nd = dev_rank(c, nr[k], B.is_lp);
+        if (B.dense_c && nd > 128 && B.ksplit_b == 0)
             return fail_msg("resize_rank: this cone's dense objective kernel supports rank <= 128");
-        if (B.dense_a && nr[k] > 128 && B.ksplit_b == 0)
+        if (B.dense_a && nd > 128 && B.ksplit_b == 0)
             return fail_msg("resize_rank: this cone's dense constraint kernel supports rank <= 128");
-        if (nblocks_for((size_t)B.n, TPB / lg_for(nr[k])) > c->maxpart)
+        if (nblocks_for((size_t)B.n, TPB / lg_for(nd)) > c->maxpart)
             return fail_msg("resize_rank: cone dimension too large for the partial-sum slots at this rank");
     }
     double *old[4] = {c->R, c->U, c->V, c->G};
     std::vector<size_t> off_old(c->nb);
-    std::vector<int> r_old(c->nb);
-    for (int k = 0; k < c->nb; ++k) { off_old[k] = c->blk[k].off; r_old[k] = c->blk[k].r; }
+    std::vector<int> r_old(c->nb), rl_old(c->nb);
+    for (int k = 0; k < c->nb; ++k) { off_old[k] = c->blk[k].off; r_old[k] = c->blk[k].r; rl_old[k] = c->blk[k].rl; }
     c->R = c->U = c->V = c->G = nullptr; // (kept alive across free_factors)
     free_factors(c);
     invalidate_t(c);
-    for (int k = 0; k < c->nb; ++k) c->blk[k].r = nr[k];
+    for (int k = 0; k < c->nb; ++k) { c->blk[k].rl = nr[k]; c->blk[k].r = dev_rank(c, nr[k], c->blk[k].is_lp); }
     refresh_merged(c);
     if (alloc_factors(c)) { for (auto p : old) hipFree(p); return 1; }
     double *now[4] = {c->R, c->U, c->V, c->G};
     for (int a = 0; a < 4; ++a)
         for (int k = 0; k < c->nb; ++k) {
             const Block &B = c->blk[k];
-            const int aug = B.r - r_old[k], rr = std::min(B.n, aug);
+            const int aug = B.rl - rl_old[k], rr = std::min(B.n, aug);
             const size_t len = (size_t)B.n * B.r;
-            LAUNCH(k_grow_rank, grid1d(len), len, r_old[k], B.r, (const double *)(old[a] + off_old[k]), now[a] + B.off, rr,
+            LAUNCH(k_grow_rank, grid1d(len), len, rl_old[k], r_old[k], B.rl, B.r, (const double *)(old[a] + off_old[k]), now[a] + B.off, rr,
                    rr > 0 ? 1 / std::sqrt((double)rr) : 0.0);
         }
     HC(hipMemsetAsync(c->ring_ab, 0, sizeof(double) * (size_t)2 * c->L, c->stream));
@@ -1428,7 +1438,7 @@ int lorads_hip_operator_kind(lorads_hip_ctx *c, int32_t k, int32_t *kind) {
 int lorads_hip_block_image(lorads_hip_ctx *c, int32_t k, int64_t im[16]) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
     const Block &B = c->blk[k];
-    const int64_t v[16] = {B.n, B.r, B.nrow, B.na, B.nc, B.pa.ne, B.pu.ne, B.dense_c, B.dense_a ? B.nd : 0, B.diag_only, B.entry_only,
+    const int64_t v[16] = {B.n, B.rl, B.nrow, B.na, B.nc, B.pa.ne, B.pu.ne, B.dense_c, B.dense_a ? B.nd : 0, B.diag_only, B.entry_only,
                            B.use_cw, B.has_gram, B.front_cw, B.cell_w, B.bip_n[0]};
     for (int i = 0; i < 16; ++i) im[i] = v[i];
     return 0;
@@ -1456,7 +1466,7 @@ int lorads_hip_graph_stats(lorads_hip_ctx *c, int64_t stats[4]) {
 int lorads_hip_algorithmic_bytes(lorads_hip_ctx *c, int32_t k, double *mv, double *cg) {
     if (k < 0 || k >= c->nb) return fail_msg("bad block");
     const Block &B = c->blk[k]; // (from the CURRENT rank: phase 1 may have grown it since the cone was built)
-    const double F = 8.0 * (double)B.n * (double)B.r;
+    const double F = 8.0 * (double)B.n * (double)B.rl; // (the problem's rank, not the padded one)
     *mv = 4 * F + 32.0 * B.na + 16.0 * B.nrow;
     *cg = *mv + 9 * F;
     return 0;

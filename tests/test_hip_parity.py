@@ -948,6 +948,57 @@ def test_lockstep_carriers_at_iteration_limits_and_later_restarts(built, monkeyp
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("name,tlr", [("maxcut800", 1.9), ("rand4000", 2.9), ("blk4x60", None), ("mix4", None), ("densec40", None), ("sdplp40", None)])
+def test_odd_ranks_run_padded_to_even_and_agree_with_the_unpadded_run(built, monkeypatch, name, tlr):
+    """A cone of odd rank runs as the next even rank with a zero column in every factor (Block::rl / r: 16-byte row accesses and the
+    kernels that need them for every rank) -- against the same work at the rank as it is (LORADS_PAD_ODD_RANK=0).  What the caller
+    sees has the cone's own rank: set / get round trips, rank growth by an odd and by an even number of columns (old columns kept,
+    new ones as AUG_RANK writes them), the first phase-1 gradient; then whole solves, which must end at the same objectives with the
+    same amount of work up to the order of the row sums."""
+    path = common.instance_path(name) if name not in ("rand4000",) else _gen(name)
+    res = []
+    for pad in ("1", "0"):
+        monkeypatch.setenv("LORADS_PAD_ODD_RANK", pad)
+        params = dict(phase1Tol=1e-3) if tlr is None else dict(phase1Tol=1e-3, timesLogRank=tlr)
+        s = common.hip_session(path, **params)
+        try:
+            ranks0 = [s.block_shape(k)[1] for k in range(s.nblk)]
+            assert any(r % 2 == 1 for r in ranks0), ranks0                   # (the case is about odd ranks)
+            assert [s.hip_block_image(k)["rank"] for k in range(s.nblk)] == ranks0
+            U0 = s.be.get_mat(host.MAT_U, 0)
+            assert U0.shape[1] == ranks0[0]
+            s.be.set_mat(host.MAT_U, 0, U0)
+            assert np.array_equal(s.be.get_mat(host.MAT_U, 0), U0)
+            grown = [min(r + (3 if k % 2 == 0 else 2), s.block_shape(k)[0]) for k, r in enumerate(ranks0)]
+            Rpre = [s.be.get_mat(host.MAT_R, k) for k in range(s.nblk)]
+            s.be.resize_rank(grown)
+            assert [s.hip_block_image(k)["rank"] for k in range(s.nblk)] == grown
+            for k in range(s.nblk):
+                R = s.be.get_mat(host.MAT_R, k)
+                n, r = Rpre[k].shape
+                assert R.shape == (n, grown[k]) and np.array_equal(R[:, :r], Rpre[k])
+                rr = min(n, grown[k] - r)
+                want = np.zeros((n, grown[k] - r))
+                want[np.arange(rr), np.arange(rr)] = 1 / np.sqrt(rr)
+                assert np.array_equal(R[:, r:], want)
+            s.be.init_constr(host.PAIR_RR)
+            g0 = s.be.alm_cal_grad(1.0)
+        finally:
+            s.close()
+        s = common.hip_session(path, **params)     # ... and a whole solve from the start point
+        try:
+            s.solve()
+            res.append((g0, s.results()))
+        finally:
+            s.close()
+    (ga, a), (gb, b) = res
+    print(name, "first gradient", ga, gb, "alm inner", a["alm_inner"], b["alm_inner"], "admm", a["admm_iter"], b["admm_iter"], "pObj", a["pObj"], b["pObj"])
+    assert ga == pytest.approx(gb, rel=1e-12)
+    # (two solves that differ in rounding stop at the same tolerance, not at the same digits: phase2Tol = 1e-5)
+    assert a["pObj"] == pytest.approx(b["pObj"], rel=1e-4) and a["dObj"] == pytest.approx(b["dObj"], rel=1e-4)
+    assert a["alm_inner"] == pytest.approx(b["alm_inner"], rel=0.1, abs=3) and a["admm_iter"] == pytest.approx(b["admm_iter"], rel=0.1, abs=3)
+
+
 @pytest.mark.parametrize("name,tlr", [("matcomp60", None), ("matcomp4000", 3.0)])
 def test_bipartite_entry_operator_equals_the_one_kernel_form(built, monkeypatch, name, tlr):
     """Single-entry cones whose entry graph is bipartite (matrix completion): k_op_entry_bip forms every entry's pair dot once, on
