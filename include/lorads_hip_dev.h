@@ -56,6 +56,14 @@ int lorads_hip_presolve_stats(lorads_hip_ctx *ctx, int64_t stats[2]);
 /* evaluations of separable shards whose four scalars the ranks' hosts have summed (lorads_hip_set_scalar_exchange) instead of a
  * collective on the stream */
 int lorads_hip_scalar_exchange_count(lorads_hip_ctx *ctx, int64_t *n);
+/* the one-launch ADMM iteration of contexts whose cones are all of Max-Cut type (lorads_amd/csrc/hip/persist.inc; LORADS_PERSIST=0
+ * switches it off): stats = {ADMM iterations run as one launch, 1 if the form is available for this context now, workgroups of
+ * the launch, rows per 8-lane group, column steps, bytes of LDS per workgroup} */
+int lorads_hip_persist_stats(lorads_hip_ctx *ctx, int64_t stats[6]);
+/* enable != 0: the leader workgroup of cone 0's team leaves the 100 MHz clock at its phase boundaries in every such launch;
+ * ticks[0..15] = those of the latest launch {start, U front done, U solve done, V front done, V solve done, evaluation done,
+ * hand-over begins, 0 ...} (reads after synchronising the stream) */
+int lorads_hip_persist_stamps(lorads_hip_ctx *ctx, int32_t enable, uint64_t ticks[16]);
 
 #ifdef __cplusplus
 }

@@ -465,6 +465,7 @@ struct Ring {
     double *s = nullptr, *y = nullptr;
 };
 struct GraphCache; // captured launch chains (graph.inc)
+struct PersistPlan; // the one-launch ADMM iteration of Max-Cut-type cones (persist.inc)
 
 } // namespace
 
@@ -523,6 +524,10 @@ struct lorads_hip_ctx {
     bool opt_graph_batched = false;          // LORADS_GRAPH=2: the lockstep sweep of a merged cone is replayed too
     bool opt_graph_forced = false;           // LORADS_GRAPH=1 or 2: replay whatever the size (default: small cones only, see graph_ok)
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
+    PersistPlan *persist = nullptr;          // teams of resident workgroups, one launch per ADMM iteration (persist.inc; LORADS_PERSIST=0: off)
+    bool opt_persist = true;                 // (read at creation)
+    bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
+    long long n_persist = 0;                 // ADMM iterations run that way
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
     // from the updated multipliers and stores them to lambda_alt, then the two vectors swap); sent off as k_dual_update
@@ -648,6 +653,7 @@ inline int dev_rank(const lorads_hip_ctx *c, int r, bool is_lp) { return (c->opt
 
 #include "build.inc"
 #include "sweep.inc"
+#include "persist.inc"
 
 } // namespace
 
@@ -746,6 +752,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipMemset(c->st, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
     if (dalloc(&c->st_shadow, (size_t)std::max(2 * c->nb, 1))) return 1;
     HC(hipMemset(c->st_shadow, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
+    c->persist = new PersistPlan();
+    c->opt_persist = !(getenv("LORADS_PERSIST") && getenv("LORADS_PERSIST")[0] == '0');
     HC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -775,6 +783,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket); hipFree(c->seg_rr_alt); hipFree(c->seg_tile_info);
     hipFree(c->ring_ab); hipFree(c->par); hipFree(c->seq_dev);
     graph_cache_free(c);
+    if (c->persist) { c->persist->release(); delete c->persist; c->persist = nullptr; }
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->h_flag) hipHostFree(c->h_flag);
@@ -1199,7 +1208,8 @@ int lorads_hip_update_dual_var(lorads_hip_ctx *c, double rho) {
     // (lockstep sweep of a Max-Cut-type merged cone that sees every constraint: its U front takes it, see enqueue_batched)
     const bool merged_front = c->has_merged && c->opt_seg_carry_dual && c->merged.diag_only && c->merged.rc_w > 0 && c->merged.w_uv &&
                               c->merged.nrow == c->m && c->opt_front_diag && !c->opt_split_front && !shard_vec(c) && !getenv("LORADS_NO_BATCH");
-    if (c->opt_lazy_scalars && c->lambda_alt && ((c->nb == 1 && (!shard_vec(c) || front_cw_ok(c, c->blk[0]))) || merged_front)) {
+    if (c->opt_lazy_scalars && c->lambda_alt && ((c->nb == 1 && (!shard_vec(c) || front_cw_ok(c, c->blk[0]))) || merged_front ||
+                                                 (c->persist && !c->persist->failed && persist_eligible(c)))) {
         flush_pending(c);
         c->pend_dual = true;
         c->pend_dual_rho = rho;
@@ -1446,6 +1456,30 @@ int lorads_hip_block_image(lorads_hip_ctx *c, int32_t k, int64_t im[16]) {
 
 int lorads_hip_scalar_exchange_count(lorads_hip_ctx *c, int64_t *n) {
     *n = c->n_sx;
+    return 0;
+}
+
+int lorads_hip_persist_stats(lorads_hip_ctx *c, int64_t stats[6]) {
+    const bool ok = c->persist && persist_ready(c, 800);
+    stats[0] = c->n_persist;
+    stats[1] = ok ? 1 : 0;
+    stats[2] = ok ? c->persist->grid : 0;
+    stats[3] = ok ? c->persist->rows : 0;
+    stats[4] = ok ? c->persist->ns : 0;
+    stats[5] = ok ? (int64_t)c->persist->lds : 0;
+    return 0;
+}
+
+int lorads_hip_persist_stamps(lorads_hip_ctx *c, int32_t enable, uint64_t ticks[16]) {
+    flush_pending(c);
+    HC(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 16; ++i) ticks[i] = 0;
+    if (c->persist && c->persist->valid && c->persist->stamps && c->persist_stamps) {
+        HC(hipMemcpy(c->persist->h_stamps, c->persist->stamps, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) ticks[i] = c->persist->h_stamps[i];
+        HC(hipMemset(c->persist->stamps, 0, sizeof(unsigned long long) * 16));
+    }
+    c->persist_stamps = enable != 0;
     return 0;
 }
 

@@ -450,6 +450,23 @@ class Session:
         _check(lib.lorads_hip_graph_stats(ctx, out), "graph_stats")
         return dict(zip(["captured", "replayed", "held", "enabled"], [int(out[i]) for i in range(4)]))
 
+    def hip_persist_stats(self):
+        """the one-launch ADMM iteration of Max-Cut-type cones (csrc/hip/persist.inc): {iterations run that way, available now,
+        workgroups, rows per lane group, column steps, LDS bytes}"""
+        lib, ctx = self._hip()
+        out = (C.c_int64 * 6)()
+        lib.lorads_hip_persist_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_persist_stats(ctx, out), "persist_stats")
+        return dict(zip(["iterations", "available", "workgroups", "rows", "column_steps", "lds_bytes"], [int(out[i]) for i in range(6)]))
+
+    def hip_persist_stamps(self, enable=True):
+        """100 MHz clock of cone 0's leader workgroup at the phase boundaries of the latest one-launch iteration (0: not taken)"""
+        lib, ctx = self._hip()
+        out = (C.c_uint64 * 16)()
+        lib.lorads_hip_persist_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        _check(lib.lorads_hip_persist_stamps(ctx, 1 if enable else 0, out), "persist_stamps")
+        return [int(out[i]) for i in range(16)]
+
     def hip_presolve_stats(self):
         """{device: patterns built by the device sorts, checked: of these compared with the host construction}"""
         lib, ctx = self._hip()

@@ -316,6 +316,8 @@ NAMED = {
     # separable cones of different size and kind, equal rank 9: the lockstep (batched) sweep with row padding
     "mix4": lambda: block_diag([maxcut(60, 90, 61), randsparse(70, 45, 62, c_edges=90, n_diag=2, n_off=3, r0=3),
                                 maxcut(66, 100, 63), matcomp(35, 33, 220, 3, 64)]),
+    # Max-Cut cones of unequal size (and therefore unequal rank, data/lorads_solver.c:290-319), separable: one team of workgroups each
+    "blkmix5": lambda: block_diag([maxcut(90, 140, 71), maxcut(120, 250, 72), maxcut(150, 400, 73), maxcut(260, 900, 74), maxcut(200, 500, 75)]),
     "densec300": lambda: randsparse(300, 60, 778, n_diag=2, n_off=4, r0=3, dense_c=True),  # dense C -> MFMA C.X path
     "densea300": lambda: with_dense_constraints(randsparse(300, 60, 783, c_edges=900, n_diag=2, n_off=4, r0=3), 4, 784),  # dense A_i -> MFMA path
     "denseac200": lambda: with_dense_constraints(randsparse(200, 40, 785, n_diag=2, n_off=4, r0=3, dense_c=True), 3, 786),  # dense C AND dense A_i
@@ -334,6 +336,8 @@ NAMED = {
     "rand20000": lambda: randsparse(20000, 5000, 20001, c_edges=120000),  # cfg3b (headline bench)
     "blk16x4000": lambda: blockdiag_maxcut(16, 4000, 24000, 4000),  # cfg4
     "matcomp50000": lambda: matcomp(25000, 25000, 200000, 10, 50000),  # cfg5
+    # cfg4's shape with cones of unequal size, n_k in [2000, 6000] (unequal ranks: VERDICT r3 #6)
+    "blk16var": lambda: block_diag([maxcut(2000 + 250 * k, 6 * (2000 + 250 * k), 4100 + k) for k in range(16)]),
 }
 
 
