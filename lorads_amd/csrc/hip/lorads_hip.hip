@@ -526,6 +526,7 @@ struct lorads_hip_ctx {
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
     PersistPlan *persist = nullptr;          // teams of resident workgroups, one launch per ADMM iteration (persist.inc; LORADS_PERSIST=0: off)
     bool opt_persist = true;                 // (read at creation)
+    bool opt_persist_l2 = true;              // granules / rows of workgroups verified to share an XCD go through its L2 (LORADS_PERSIST_L2=0: always written through)
     bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
     long long n_persist = 0;                 // ADMM iterations run that way
     bool use_publish = true;
@@ -754,6 +755,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     HC(hipMemset(c->st_shadow, 0, sizeof(CGState) * (size_t)std::max(2 * c->nb, 1)));
     c->persist = new PersistPlan();
     c->opt_persist = !(getenv("LORADS_PERSIST") && getenv("LORADS_PERSIST")[0] == '0');
+    c->opt_persist_l2 = !(getenv("LORADS_PERSIST_L2") && getenv("LORADS_PERSIST_L2")[0] == '0');
     HC(hipDeviceSynchronize());
     *out = c;
     return 0;
