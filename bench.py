@@ -425,6 +425,71 @@ def cpu_baseline(path, tlr, rho, state_file, budget_s, log_fn, n_max=0, ranks=No
                       "plain-C restatement (oracle/) on 1 host core" % (its, cg)}
 
 
+def parity_sharded(s, path, tlr, rho, dist, torch, device, world, rank, host, iters=5):
+    """The sharded run against the SINGLE-RANK run of the same problem from the same state: every rank re-installs
+    its own (U, V, lambda), evaluates and runs `iters` ADMM iterations with the cross-rank sums of this run; rank 0 then opens the whole
+    problem on its own GPU, loads the ranks' state into it and runs the same iterations.  Block-separable constraints: the ranks'
+    Jacobi sweep is the single rank's Gauss-Seidel sweep, so the CG iteration counts must be EQUAL and the objectives
+    agree to 1e-10.  Returns the block for the JSON line (rank 0; None elsewhere); "ok" is what the exit code follows."""
+    be = s.be
+    nloc = s.nblk
+    UV = [(be.get_mat(host.MAT_U, j), be.get_mat(host.MAT_V, j)) for j in range(nloc)]
+    lam = be.get_vec(host.VEC_LAMBDA)
+    ranks_loc = [s.block_info(j)["rank"] for j in range(nloc)]
+
+    def run(sess, mats, lam_vec):
+        b = sess.be
+        for j, (U, V) in enumerate(mats):
+            b.set_mat(host.MAT_U, j, U)
+            b.set_mat(host.MAT_V, j, V)
+        b.set_vec(host.VEC_LAMBDA, lam_vec)
+        b.init_constr(host.PAIR_UV)
+        b.cal_obj(host.PAIR_UV)
+        e0 = b.update_dimacs(host.PAIR_UV)
+        e1, cg, p, d = admm_steps(b, host, rho, e0, iters, sess)
+        return e0, e1, int(cg), p, d
+
+    e0, e1, cg, p, d = run(s, UV, lam)
+    t = torch.tensor([float(cg)], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    cg_all = int(t.item())
+    box = [None] * world
+    dist.gather_object((rank, UV, lam, np.asarray(s.constraint_map), ranks_loc), box if rank == 0 else None, dst=0)
+    out = None
+    if rank == 0:
+        try:
+            one = host.Session.open(path)
+            one.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+            one.prepare(1, 0, separable=False)
+            one.attach_hip()
+            try:
+                nb = one.nblk
+                mats, rk = [None] * nb, [None] * nb
+                lam_all = np.zeros(one.m)
+                for (r_, uv, lm, cmap, rl) in box:
+                    for j, m_ in enumerate(uv):      # cones are dealt round robin: local cone j of rank r is cone r + j * world of the file
+                        mats[r_ + j * world] = m_
+                        rk[r_ + j * world] = rl[j]
+                    lam_all[cmap] = lm
+                if [one.block_info(k)["rank"] for k in range(nb)] != rk:   # (phase 1 has grown the ranks: AUG_RANK)
+                    one.be.resize_rank(rk)
+                f0, f1, cg1, p1, d1 = run(one, mats, lam_all)
+            finally:
+                one.close()
+            rel = lambda x, y: abs(x - y) / (1.0 + abs(y))  # noqa: E731
+            out = {"what": "%d ADMM iterations from the same (U, V, lambda): %d ranks against ONE rank holding the whole problem" % (iters, world),
+                   "iterations": iters, "cg_iters_sharded": cg_all, "cg_iters_single_rank": cg1,
+                   "pObj_sharded": p, "pObj_single_rank": p1, "pObj_rel_diff": rel(p, p1),
+                   "dObj_sharded": d, "dObj_single_rank": d1, "dObj_rel_diff": rel(d, d1),
+                   "err1_start_sharded": e0, "err1_start_single_rank": f0, "err1_sharded": e1, "err1_single_rank": f1}
+            out["ok"] = bool(cg_all == cg1 and out["pObj_rel_diff"] <= 1e-10 and out["dObj_rel_diff"] <= 1e-10 and
+                             abs(e1 - f1) <= 1e-6 * abs(f1) + 1e-13)
+        except Exception as e:  # noqa: BLE001
+            out = {"ok": False, "what": "failed: %s" % e}
+    dist.barrier()
+    return out
+
+
 def hip_source_hash():
     """sha256 over the HIP sources the kernels are built from (what a committed profile must have been taken from)"""
     import hashlib
@@ -493,7 +558,11 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     if prof_early:
         s.hip_profile(1, 1 << 30)
     t0 = time.time()
+    s.hip_sync()
+    t_p1 = time.perf_counter()
     s.alm()
+    s.hip_sync()
+    t_p1 = time.perf_counter() - t_p1
     s.alm_to_admm()
     res = s.results()
     rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
@@ -560,6 +629,8 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     # because it is timed.
     roof_samples, front_samples, alone_ms = [], [], None
     fronts_per_step = 2.0 * nloc
+    pstat = s.hip_persist_stats()
+    one_launch = pstat["available"] == 1 and pstat["iterations"] > 0   # (the whole iteration is one launch: that launch is what is timed)
     if a.roofline_samples > 0:
         per_step = prof["matvec_launches"] / max(a.steps, 1)
         if dist:   # every rank must run the same number of (collective-carrying) iterations
@@ -567,7 +638,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             per_step = float(t.item())
         per_step = max(per_step, 0.25)
-        for target, per, sink in ((0, per_step, roof_samples), (1, fronts_per_step, front_samples)):
+        for target, per, sink in ((0, 1.0 if one_launch else per_step, roof_samples), (1, fronts_per_step, front_samples)):
+            if one_launch and target == 1:
+                continue
             todo = int(min(4000, np.ceil(a.roofline_samples / per))) + 2
             chunk = int(max(1, min(todo, 600 // max(1.0, 1.5 * per))))  # (event pool: 1024 samples)
             s.hip_profile_target(target)
@@ -580,7 +653,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         s.hip_profile_target(0)
         try:
             reps = 200
-            alone_ms = s.hip_time_operator(reps) / reps
+            alone_ms = None if one_launch else s.hip_time_operator(reps) / reps
         except Exception as e:  # noqa: BLE001
             log("rank %d: back-to-back operator run unavailable: %s" % (rank, e))
     b_mv = b_cg = 0.0
@@ -628,6 +701,15 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             # (patterns, adjacency, slot lists, uploads) built inside lorads_hip_create
             "setup_seconds": {"read_and_presolve_host": t_setup1 - t_setup0, "device_image_in_create": t_setup2 - t_setup1},
             "roofline": None,
+            # BM / ALM warm start (phase 1; lorads_alm.c:1066-1131), untimed by the contract, reported beside it: the
+            # solver's own phase 1 on the GPU from the reference's start point to --phase1Tol 1e-2
+            "phase1": None if not res["alm_inner"] else {
+                "inner_iters": int(res["alm_inner"]), "outer_iters": int(res["alm_outer"]), "seconds": t_p1,
+                "inner_iters_per_s": res["alm_inner"] / t_p1, "us_per_inner_iter": 1e6 * t_p1 / res["alm_inner"]},
+            "one_launch_iteration": None if not one_launch else {
+                "what": "every cone of Max-Cut type: one launch per ADMM iteration, teams of resident workgroups (csrc/hip/persist.inc)",
+                "workgroups": pstat["workgroups"], "rows_per_lane_group": pstat["rows"], "column_steps": pstat["column_steps"],
+                "lds_bytes_per_workgroup": pstat["lds_bytes"]},
         }
         # ---- roofline of the DOMINANT kernel of the timed iterations, from the launches those iterations make (events on the
         # library's stream, untimed pass): algorithmic bytes per launch / median launch duration / 8 TB/s
@@ -641,7 +723,20 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         op_ms, fr_ms = med(roof_samples), med(front_samples)
         cw_front = op_kernels.startswith("k_cw")   # (the one-kernel front also leaves iteration 0's constraint-value contributions)
         groups = {}
-        if op_ms:
+        if one_launch and op_ms:
+            # the whole ADMM iteration is ONE launch (k_admm_diag): its algorithmic bytes are SURVEY 8d's per-iteration sum with the CG
+            # iteration counts this run measured -- solves (K + 1 + ceil(K / 20)) B_mv + 9 F K + 3 F each, two right-hand sides, four
+            # constraint evaluations, the objective, the m-vector passes -- although most of them never leave the chip here
+            k_loc = cg_iters / max(a.steps, 1) / world   # CG iterations per ADMM iteration in this rank's cones (average over the ranks)
+            b_obj = 3.0 * F + 16.0 * nc
+            b_iter = b_mv * (k_loc / nloc + 4.0) + 9.0 * (F / nloc) * k_loc + 6.0 * F + 2.0 * b_rhs + 4.0 * b_half + b_obj + 32.0 * m_
+            groups["admm_iteration_one_launch"] = {
+                "kernel": "k_admm_diag: fronts, CG solves, constraint refresh, evaluation and hand-over of one ADMM iteration in one launch",
+                "algorithmic_bytes_per_launch": b_iter, "avg_launch_ms": op_ms, "achieved": b_iter / (op_ms * 1e-3) / 1e9,
+                "frac": b_iter / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_per_step": 1.0, "events": stat(roof_samples),
+                "bytes": "SURVEY 8d per-iteration sum at %.2f CG iterations per iteration: the bytes the launch-by-launch algorithm "
+                         "moves; the factors stay in registers here, so the launch's own HBM traffic (PMC) is a fraction of it" % k_loc}
+        elif op_ms:
             groups["cg_operator"] = {
                 "kernel": "CG operator application x + A_V^*(A_V x) as the iterations run it: %s" %
                           ("k_wsum + k_spmm_ell (iteration 0: the constraint values come out of the front), k_cw + k_spmm_ell otherwise"
@@ -687,8 +782,9 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         # of this run (a profile of older kernels is not this run's evidence)
         if dom:
             pm, tsrc = traffic_from_profiles(workload)
-            tr = (pm or {}).get("solve_front" if dom == "solve_front" else "cg_operator_application", {}).get("traffic_bytes")
-            dom_kernels = ("k_front_cw" if cw_front else "k_spmm2") if dom == "solve_front" else \
+            tr = (pm or {}).get({"solve_front": "solve_front", "admm_iteration_one_launch": "admm_iteration_one_launch"}.get(dom, "cg_operator_application"), {}).get("traffic_bytes")
+            dom_kernels = "k_admm_diag" if dom == "admm_iteration_one_launch" else \
+                          ("k_front_cw" if cw_front else "k_spmm2") if dom == "solve_front" else \
                           ("k_wsum+k_spmm_ell" if cw_front else op_kernels)
             pms, psrc = rocprof_from_profiles(workload, dom_kernels)
             for val, src, key in ((tr, tsrc, "traffic"), (pms, psrc, "rocprofv3")):
@@ -750,6 +846,10 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         else:
             out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s", "cores": 0, "kind": "reference",
                                    "sample": "timed at N=1 only"}
+    if dist and world > 1 and s.separable and os.environ.get("LORADS_BENCH_PARITY", "1") != "0":
+        ps = parity_sharded(s, path, tlr, rho, dist, torch, device, world, rank, host)
+        if out is not None:
+            out["parity_sharded"] = ps
     if os.environ.get("LORADS_PRINT_CPU"):
         with open("/proc/self/stat") as fh:
             cpu_now = int(fh.read().rsplit(")", 1)[1].split()[36])
@@ -793,10 +893,11 @@ def spawn_ranks(a, argv):
             pr.kill()
             rcs.append(pr.wait())
     line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if line:
+        print(line[-1], flush=True)   # (also when a check failed: the line says which)
     if any(rcs) or not line:
         log("bench.py: ranks exited with codes %s%s" % (rcs, "" if line else "; no JSON line from rank 0"))
         sys.exit(1)
-    print(line[-1], flush=True)
 
 
 def main():
@@ -821,6 +922,7 @@ def main():
     ap.add_argument("--roofline-samples", type=int, default=200, help="untimed pass after the timed region: every operator "
                     "application timed with HIP events until this many samples exist")
     a = ap.parse_args()
+    explicit_workload = a.workload is not None or a.scaling == "strong"
     if a.workload is None:
         a.workload = "blk16x4000" if a.scaling == "strong" else "rand20000"
     if a.times_log_rank is None:
@@ -839,6 +941,8 @@ def main():
     dist = None
     # rehearsal knobs (1-GPU box): LORADS_DIST_BACKEND=gloo LORADS_FORCE_DEVICE=0 run N ranks on one card
     backend = os.environ.get("LORADS_DIST_BACKEND", "nccl")
+    if "LORADS_FORCE_DEVICE" in os.environ and world > 1:   # several ranks on one card: their one-launch iterations take turns (persist.inc)
+        os.environ.setdefault("LORADS_SHARED_GPU", "1")
     dev_index = int(os.environ.get("LORADS_FORCE_DEVICE", local_rank if world > 1 else 0))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -859,17 +963,41 @@ def main():
     from lorads_amd import host
 
     out = run_workload(a, a.workload, torch, dist, device, world, rank, host, not a.no_cpu)
+    if world > 1 and not a.no_extra and not explicit_workload:
+        # N > 1 as the driver calls it (no --workload / --scaling): the weak replica line above AND BASELINE config 4 -- the 16 cones of
+        # ONE blk16x4000 problem dealt over the N ranks (strong scaling) -- as `extra`, each with ranks_seen, the exchange and a sharded
+        # parity block
+        import copy
+        a2 = copy.copy(a)
+        a2.scaling = "strong"
+        ex = run_workload(a2, "blk16x4000", torch, dist, device, world, rank, host, False, tlr=2.0)
+        if rank == 0:
+            keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "scaling", "ranks_seen",
+                    "scalar_exchange", "cg_iters_per_s", "cg_iters_per_admm_iter", "config", "roofline", "state", "parity_sharded",
+                    "one_launch_iteration", "phase1")
+            out["extra"] = [{k: ex[k] for k in keys if k in ex}]
     if rank == 0 and world == 1 and a.workload == "rand20000" and not a.no_extra:
         # the north-star target sentence is phrased on Max-Cut n = 20000, r = 40 (cfg3a): reported beside the headline
         keys = ("value", "unit", "ms_per_step", "ms_per_step_median", "cg_iters_per_s", "cg_iters_per_admm_iter", "config", "roofline",
-                "cpu_baseline", "state", "parity_full_size", "speedup_vs_cpu_1core")
+                "cpu_baseline", "state", "parity_full_size", "speedup_vs_cpu_1core", "phase1", "one_launch_iteration")
         ex = run_workload(a, "maxcut20000", torch, dist, device, world, rank, host, not a.no_cpu, tlr=4.0)
         out["extra"] = [{k: ex[k] for k in keys if k in ex}]
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    rc = 0
     if rank == 0:
         print(json.dumps(out), flush=True)
+        # a run that silently had fewer ranks than --gpus, or whose sharded iterations differ from the single-rank ones, must not pass
+        for line in [out] + list(out.get("extra") or []):
+            if world > 1 and line.get("ranks_seen") not in (None, world):
+                log("bench.py: ranks_seen %s != %d" % (line.get("ranks_seen"), world))
+                rc = 2
+            if line.get("parity_sharded") is not None and not line["parity_sharded"].get("ok"):
+                log("bench.py: sharded parity check failed: %s" % json.dumps(line["parity_sharded"]))
+                rc = 2
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,10 @@
 // 64-lane __shfl_xor butterflies.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -526,6 +530,7 @@ struct lorads_hip_ctx {
     GraphCache *graphs = nullptr;            // captured launch chains by shape (graph.inc)
     PersistPlan *persist = nullptr;          // teams of resident workgroups, one launch per ADMM iteration (persist.inc; LORADS_PERSIST=0: off)
     bool opt_persist = true;                 // (read at creation)
+    int shared_gpu_fd = -1;                  // LORADS_SHARED_GPU=1: lock file of the device (several processes on one card take turns, see run_sweep_persist)
     bool opt_persist_l2 = true;              // granules / rows of workgroups verified to share an XCD go through its L2 (LORADS_PERSIST_L2=0: always written through)
     bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
     long long n_persist = 0;                 // ADMM iterations run that way
@@ -756,6 +761,14 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->persist = new PersistPlan();
     c->opt_persist = !(getenv("LORADS_PERSIST") && getenv("LORADS_PERSIST")[0] == '0');
     c->opt_persist_l2 = !(getenv("LORADS_PERSIST_L2") && getenv("LORADS_PERSIST_L2")[0] == '0');
+    if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
+        int dev = 0;
+        char bus[64] = "0";
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+        for (char *q = bus; *q; ++q) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
+        const std::string path = std::string("/tmp/lorads_gpu_") + bus + ".lock";
+        c->shared_gpu_fd = open(path.c_str(), O_CREAT | O_RDWR, 0666);
+    }
     HC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -786,6 +799,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     hipFree(c->ring_ab); hipFree(c->par); hipFree(c->seq_dev);
     graph_cache_free(c);
     if (c->persist) { c->persist->release(); delete c->persist; c->persist = nullptr; }
+    if (c->shared_gpu_fd >= 0) close(c->shared_gpu_fd);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
     if (c->h_flag) hipHostFree(c->h_flag);

@@ -10,12 +10,19 @@
  * values into slot[r].buf[s & 1], store-release its sequence word = s, then for q = 0 .. world-1 load-acquire slot[q].buf[s & 1].seq
  * until it equals s and add that rank's values -- in rank order, so every rank forms the SAME sum bit for bit.  A rank can only be
  * one call ahead of the slowest reader of a buffer: to enter call s + 2 it has left call s + 1, for which every rank had written
- * s + 1, i.e. had left call s.  A rank that never arrives (a dead process) ends the wait after LORADS_HANDOVER_TIMEOUT_S seconds. */
+ * s + 1, i.e. had left call s.  A rank that never arrives (a dead process) ends the wait after LORADS_HANDOVER_TIMEOUT_S seconds.
+ *
+ * Opening: rank 0 unlinks whatever carries the name, makes the segment and writes its pid next to the magic word.  The other ranks
+ * attach only to a segment that (a) still carries its name after they have read the magic word -- one that rank 0 has replaced in the
+ * meantime has no link left -- and (b) whose maker is alive: the leftover of a run that died (a fixed rendezvous port gives every run of
+ * a user the same name) is refused and the wait for rank 0's fresh one goes on.  Callers that can should still put a barrier between
+ * rank 0's open and the others' (bench.py does): it turns the wait into a formality. */
 #include "lorads_host.h"
 
 #include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,10 +45,12 @@ typedef struct {
 typedef struct {
     volatile uint64_t magic;
     int32_t world;
-    char pad[256 - 12];
+    int32_t owner_pid;        /* the rank-0 process that made this segment: a segment whose maker is gone is a leftover, not an invitation */
+    char pad[256 - 16];
 } shmx_head;
 
 struct lrd_shmx {
+    ino_t ino;                /* of the mapped segment */
     char name[128];
     int world, rank, owner;
     uint64_t call;
@@ -84,6 +93,7 @@ int lrd_shmx_open(const char *name, int world, int rank, lrd_shmx **out) {
         }
     }
     void *p = mmap(NULL, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    { struct stat st0; if (fstat(fd, &st0) == 0) x->ino = st0.st_ino; }
     close(fd);
     if (p == MAP_FAILED) { if (x->owner) shm_unlink(name); free(x); return 1; }
     x->head = (shmx_head *)p;
@@ -91,14 +101,41 @@ int lrd_shmx_open(const char *name, int world, int rank, lrd_shmx **out) {
     if (x->owner) {
         memset(p, 0, x->bytes);
         x->head->world = world;
+        x->head->owner_pid = (int32_t)getpid();
         __atomic_store_n(&x->head->magic, SHMX_MAGIC, __ATOMIC_RELEASE);
     } else {
         const double t0 = now_s();
-        while (__atomic_load_n(&x->head->magic, __ATOMIC_ACQUIRE) != SHMX_MAGIC) {
+        for (;;) {
+            int fresh = 0;
+            if (__atomic_load_n(&x->head->magic, __ATOMIC_ACQUIRE) == SHMX_MAGIC) {
+                /* is what we have mapped still THE segment of that name, and is its maker alive? */
+                struct stat st_name;
+                int fd2 = shm_open(name, O_RDWR, 0600);
+                const int named = fd2 >= 0 && fstat(fd2, &st_name) == 0 && st_name.st_ino == x->ino;
+                if (fd2 >= 0) close(fd2);
+                const pid_t op = (pid_t)x->head->owner_pid;
+                const int alive = op > 0 && (kill(op, 0) == 0 || errno == EPERM);
+                fresh = named && alive;
+                if (fresh && x->head->world != world) { munmap(p, x->bytes); free(x); return 1; }
+                if (fresh) break;
+            }
             if (now_s() - t0 > 60.0) { munmap(p, x->bytes); free(x); return 1; }
-            usleep(200);
+            usleep(500);
+            /* a leftover (dead maker) or a segment rank 0 has replaced: map whatever carries the name now */
+            int fd3 = shm_open(name, O_RDWR, 0600);
+            struct stat st3;
+            if (fd3 >= 0 && fstat(fd3, &st3) == 0 && (size_t)st3.st_size >= x->bytes && st3.st_ino != x->ino) {
+                void *p3 = mmap(NULL, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd3, 0);
+                if (p3 != MAP_FAILED) {
+                    munmap(p, x->bytes);
+                    p = p3;
+                    x->ino = st3.st_ino;
+                    x->head = (shmx_head *)p;
+                    x->slot = (shmx_slot *)((char *)p + sizeof(shmx_head));
+                }
+            }
+            if (fd3 >= 0) close(fd3);
         }
-        if (x->head->world != world) { munmap(p, x->bytes); free(x); return 1; }
     }
     *out = x;
     return 0;

@@ -13,6 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _several_processes_on_one_card(monkeypatch):
+    """the ranks of these tests share the box's one GPU: their one-launch ADMM iterations (teams of resident workgroups,
+    csrc/hip/persist.inc) take turns instead of waiting for each other's compute units (the workers inherit the variable)"""
+    monkeypatch.setenv("LORADS_SHARED_GPU", "1")
+    yield
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

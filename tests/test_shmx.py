@@ -107,3 +107,50 @@ def test_bad_arguments():
     assert lib.lrd_shmx_allreduce(h, v, 3) == 0 and list(v) == [1.5, -2.0, 1e-300]
     assert lib.lrd_shmx_allreduce(h, v, 17) != 0
     lib.lrd_shmx_close(h)
+
+
+def _leftover_maker(name, world, q):
+    """a 'rank 0' of an earlier run that dies without closing: its segment stays behind under the name"""
+    lib = _lib()
+    h = C.c_void_p()
+    q.put(lib.lrd_shmx_open(name.encode(), world, 0, C.byref(h)))
+    q.close()
+    q.join_thread()      # (the answer must be out before the process goes -- without closing, let alone unlinking, anything)
+    os._exit(0)
+
+
+def _late_rank0(name, world, delay, q):
+    time.sleep(delay)
+    lib = _lib()
+    h = C.c_void_p()
+    rc = lib.lrd_shmx_open(name.encode(), world, 0, C.byref(h))
+    v = (C.c_double * 1)(1.0)
+    rc2 = lib.lrd_shmx_allreduce(h, v, 1) if rc == 0 else 1
+    q.put(("r0", rc, rc2, v[0]))
+    lib.lrd_shmx_close(h)
+
+
+def test_a_leftover_segment_of_a_dead_run_is_not_attached_to(monkeypatch, request):
+    """advisor r3: a run that died leaves a valid-looking segment of the same name (uid + rendezvous port).  A rank that opens the
+    name before the new rank 0 has replaced it must not settle on the leftover (its maker is gone): it waits for the fresh one."""
+    monkeypatch.setenv("LORADS_HANDOVER_TIMEOUT_S", "5")
+    name = "/lorads_test_%d_leftover" % os.getpid()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    dead = ctx.Process(target=_leftover_maker, args=(name, 2, q))
+    dead.start()
+    request.addfinalizer(lambda: os.path.exists("/dev/shm" + name) and os.unlink("/dev/shm" + name))
+    assert q.get(timeout=30) == 0
+    dead.join(timeout=30)
+    assert os.path.exists("/dev/shm" + name)          # the leftover is there, magic word and all
+    r0 = ctx.Process(target=_late_rank0, args=(name, 2, 1.0, q))
+    r0.start()                                         # the new rank 0 arrives a second AFTER rank 1 has started to open
+    lib = _lib()
+    h = C.c_void_p()
+    assert lib.lrd_shmx_open(name.encode(), 2, 1, C.byref(h)) == 0
+    v = (C.c_double * 1)(2.0)
+    assert lib.lrd_shmx_allreduce(h, v, 1) == 0 and v[0] == 3.0    # the two ranks met on the SAME (fresh) segment
+    tag, rc, rc2, got = q.get(timeout=30)
+    assert (rc, rc2, got) == (0, 0, 3.0)
+    lib.lrd_shmx_close(h)
+    r0.join(timeout=30)
