@@ -335,6 +335,7 @@ NAMED = {
     "maxcut20000": lambda: maxcut(20000, 120000, 20000),   # cfg3a
     "rand20000": lambda: randsparse(20000, 5000, 20001, c_edges=120000),  # cfg3b (headline bench)
     "blk16x4000": lambda: blockdiag_maxcut(16, 4000, 24000, 4000),  # cfg4
+    "blk2x4000": lambda: blockdiag_maxcut(2, 4000, 24000, 4000),    # what ONE of eight GPUs holds of cfg4 (two of its sixteen cones)
     "matcomp50000": lambda: matcomp(25000, 25000, 200000, 10, 50000),  # cfg5
     # cfg4's shape with cones of unequal size, n_k in [2000, 6000] (unequal ranks: VERDICT r3 #6)
     "blk16var": lambda: block_diag([maxcut(2000 + 250 * k, 6 * (2000 + 250 * k), 4100 + k) for k in range(16)]),
