@@ -543,8 +543,6 @@ struct lorads_hip_ctx {
     double *lambda_alt = nullptr;
     bool virt_refresh = false; // the V-solve's front forms its weights as if the refresh after the U-solve had been stored (see enqueue_sweep)
     bool opt_entry_bip = true; // single-entry cones with a bipartite entry graph: k_op_entry_bip x 2 (LORADS_ENTRY_BIP=0: k_op_entry)
-    bool opt_seg_lastblock = false; // lockstep sweep: the convergence test on k_cg_update_seg's last workgroup (LORADS_SEG_LASTBLOCK=1; measured slower than k_cg_check_seg: off)
-    int *seg_ticket = nullptr;     // its arrival counter (device, zero between launches)
     bool opt_fuse_dir = true; // Max-Cut-type cones: the direction update inside the operator kernel (LORADS_FUSE_DIR=0: k_cg_dir)
     bool opt_cw_quad = true;  // k_cw with 4 lanes per entry where it applies (LORADS_CW_QUAD=0: 8 lanes)
     bool opt_fuse_eval = true; // single cone on the k_cw path: constraint values and objective partials in one launch (LORADS_FUSE_EVAL=0)
@@ -725,7 +723,6 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_gram = !(getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '0');
     c->opt_gram_single = getenv("LORADS_LBFGS_GRAM") && getenv("LORADS_LBFGS_GRAM")[0] == '2';
     c->opt_fuse_dir = !(getenv("LORADS_FUSE_DIR") && getenv("LORADS_FUSE_DIR")[0] == '0');
-    c->opt_seg_lastblock = getenv("LORADS_SEG_LASTBLOCK") && getenv("LORADS_SEG_LASTBLOCK")[0] == '1';
     c->opt_entry_bip = !(getenv("LORADS_ENTRY_BIP") && getenv("LORADS_ENTRY_BIP")[0] == '0');
     c->opt_seg_carry = !(getenv("LORADS_SEG_CARRY") && getenv("LORADS_SEG_CARRY")[0] == '0');
     c->opt_seg_carry_init = !(getenv("LORADS_SEG_CARRY_INIT") && getenv("LORADS_SEG_CARRY_INIT")[0] == '0');
@@ -795,7 +792,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     }
     free_factors(c);
     hipFree(c->cstage); hipFree(c->sepbuf); hipFree(c->gram);
-    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_ticket); hipFree(c->seg_rr_alt); hipFree(c->seg_tile_info);
+    hipFree(c->b); hipFree(c->lambda); hipFree(c->lambda_alt); hipFree(c->csum); hipFree(c->q12); hipFree(c->part); hipFree(c->ctrl); hipFree(c->st_shadow); hipFree(c->seg_tile_cone); hipFree(c->seg_rr_alt); hipFree(c->seg_tile_info);
     hipFree(c->ring_ab); hipFree(c->par); hipFree(c->seq_dev);
     graph_cache_free(c);
     if (c->persist) { c->persist->release(); delete c->persist; c->persist = nullptr; }
