@@ -141,7 +141,16 @@ def _flags_to_params(flags):
             for i in range(0, len(flags), 2)}
 
 
-@pytest.mark.parametrize("idx", range(len(common.golden_solves())))
+def _solve_id(i):
+    e = common.golden_solves()[i]
+    # (the two dense-branch instances with several stationary points are held to the level the reference itself has converged to,
+    # 5e-4; what that bound could hide is excluded by the same-start comparison at 1e-8 in
+    # test_fullsize_admm_iterations_from_the_devices_own_state_vs_compiled_reference)
+    tag = "-objective to the references own convergence level 5e-4" if e["instance"] in ("matcomp60", "theta50") else ""
+    return "%s%s%s" % (e["instance"], "".join(e["flags"]).replace("--", "-"), tag)
+
+
+@pytest.mark.parametrize("idx", range(len(common.golden_solves())), ids=_solve_id)
 def test_whole_solve_vs_reference(built, idx):
     """Whole solves against the reference's own runs of the same command (tests/golden/solve.json), in the north-star's
     wording: converged objectives to 1e-6 relative, DIMACS errors no worse than the reference's, and -- where the

@@ -83,6 +83,13 @@ def test_reference_loops_drive_the_hip_library(built, instance, flags):
     fr = e["final_rank"] if isinstance(e["final_rank"], list) else [e["final_rank"]]
     assert [float(x) for x in g["final_rank"]] == [float(x) for x in fr]
     dense = e["wsum_is_dense"] if isinstance(e["wsum_is_dense"], list) else [e["wsum_is_dense"]]
+    if all(x == 0 for x in dense):
+        # sparse-mode instance: up to the first reopt round (phase 1, then the first ADMM pass) the reference's loops take the same
+        # decisions on the device's numbers as on its own -- inner iterations of phase 1, ADMM iterations and CG iterations of the
+        # first pass (rand120 with its reopt round is held to this too)
+        assert int(g["alm_end_inner"][0]) == int(e["alm_end_inner"]), (g["alm_end_inner"][0], e["alm_end_inner"])
+        assert int(g["admm_first_iter"][0]) == int(e["admm_first_iter"]), (g["admm_first_iter"][0], e["admm_first_iter"])
+        assert int(g["admm_first_cg"][0]) == int(e["admm_first_cg"]), (g["admm_first_cg"][0], e["admm_first_cg"])
     if all(x == 0 for x in dense) and g["reopt_rounds"][0] == 0 and e["reopt_rounds"] == 0:
         # sparse-mode instance, no reopt round: the reference's loop takes the same decisions on the device's numbers
         assert int(g["alm_inner"][0]) == int(e["alm_inner"])
