@@ -531,6 +531,7 @@ struct lorads_hip_ctx {
     PersistPlan *persist = nullptr;          // teams of resident workgroups, one launch per ADMM iteration (persist.inc; LORADS_PERSIST=0: off)
     bool opt_persist = true;                 // (read at creation)
     int shared_gpu_fd = -1;                  // LORADS_SHARED_GPU=1: lock file of the device (several processes on one card take turns, see run_sweep_persist)
+    bool opt_persist_carry = true;           // the evaluation leaves (C V) for the next iteration's U front (LORADS_PERSIST_CARRY=0: every front gathers)
     bool opt_persist_l2 = true;              // granules / rows of workgroups verified to share an XCD go through its L2 (LORADS_PERSIST_L2=0: always written through)
     bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
     long long n_persist = 0;                 // ADMM iterations run that way
@@ -655,6 +656,7 @@ inline bool shard_vec(const lorads_hip_ctx *c) { return c->ar && !c->sep; }
 // the rank the kernels run at (see Block::rl): odd ranks take a zero column along; the LP block's "rank" 1 is not a factor width
 inline int dev_rank(const lorads_hip_ctx *c, int r, bool is_lp) { return (c->opt_pad_rank && !is_lp && (r & 1) && r < 512) ? r + 1 : r; }
 
+inline void persist_touch(lorads_hip_ctx *c); // (persist.inc: what the one-launch iteration keeps between launches belongs to the V in memory)
 #include "build.inc"
 #include "sweep.inc"
 #include "persist.inc"
@@ -758,6 +760,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->persist = new PersistPlan();
     c->opt_persist = !(getenv("LORADS_PERSIST") && getenv("LORADS_PERSIST")[0] == '0');
     c->opt_persist_l2 = !(getenv("LORADS_PERSIST_L2") && getenv("LORADS_PERSIST_L2")[0] == '0');
+    c->opt_persist_carry = !(getenv("LORADS_PERSIST_CARRY") && getenv("LORADS_PERSIST_CARRY")[0] == '0');
     if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
         int dev = 0;
         char bus[64] = "0";
@@ -1241,6 +1244,7 @@ int lorads_hip_cal_dual_obj(lorads_hip_ctx *c, double *dobj) {
 }
 
 static void invalidate_t(lorads_hip_ctx *c) {
+    persist_touch(c);
     c->merged.t_uv_valid = false;
     for (auto &B : c->blk) { B.t_uv_valid = false; B.wj_for = nullptr; }
 }
@@ -1262,6 +1266,7 @@ int lorads_hip_average_uv_to_v(lorads_hip_ctx *c) {
 
 int lorads_hip_scale_obj(lorads_hip_ctx *c, double s) {
     c->ls_np = 0;
+    persist_touch(c);
     for (auto &B0 : c->blk) B0.wj_for = nullptr; // (kept products C Y of a dense objective are those of the old C)
     std::vector<Block *> all;
     for (auto &B0 : c->blk) all.push_back(&B0);
@@ -1283,6 +1288,7 @@ int lorads_hip_set_mat(lorads_hip_ctx *c, int32_t which, int32_t k, const double
     flush_pending(c);
     double *base = mat_base(c, which);
     if (!base || k < 0 || k >= c->nb) return fail_msg("set_mat: bad argument");
+    persist_touch(c);
     Block &B = c->blk[k];
     B.t_uv_valid = false;
     B.wj_for = nullptr;
@@ -1329,6 +1335,7 @@ int lorads_hip_get_vec(lorads_hip_ctx *c, int32_t which, double *v) {
 
 int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
     flush_pending(c);
+    persist_touch(c);
     // AUG_RANK (data/lorads_solver.c:806-906): keep the old columns, new columns = 1/sqrt(k) on their
     // leading diagonal (lpRandomDiag :776-786), clear L-BFGS history and CG workspaces.  Everything stays in HBM: the new
     // arrays are allocated, one kernel per factor and cone copies row i's old entries and writes the new columns, the old

@@ -112,6 +112,45 @@ def test_one_launch_iteration_equals_launch_by_launch_fullsize(built, name, tlr,
     _compare(res[0], res[1], iters, name)
 
 
+def test_carried_objective_gather_changes_nothing_but_the_objectives_rounding(built, monkeypatch):
+    """LORADS_PERSIST_CARRY (default on): the evaluation gathers V instead of R, forms (C R) = ((C U) + (C V)) / 2 from the V front's
+    (C U), and leaves (C V) for the next launch's U front (two gathers per iteration instead of three).  Against every front
+    gathering for itself: the factors, the multipliers and the CG counts are the SAME numbers bit for bit (the U front's operand is
+    the sum it would have formed), the objective <C, R R^T> differs by the rounding of one addition.  Mixed with sweeps that do not
+    evaluate, slot-by-slot entries, a changed iteration limit and set_mat in between (all of which must drop what was carried)."""
+    out = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("LORADS_PERSIST_CARRY", carry)
+        s = _session(common.instance_path("blk4x60"), True, phase1Tol=1e-2)
+        try:
+            s.alm()
+            s.alm_to_admm()
+            s.be.init_constr(host.PAIR_UV)
+            rho, log = 1.3, []
+            for it in range(40):
+                if it % 6 == 5:
+                    c = s.be.admm_update_var(rho, 1e-8, 800)
+                    p, d, e = s.be.cal_obj(host.PAIR_UV), s.be.cal_dual_obj(), s.be.update_dimacs(host.PAIR_UV)
+                else:
+                    c, p, d, e = s.be.admm_step(rho, 1e-8 if it % 4 else 1e-3, 800 if it != 17 else 2)
+                s.be.update_dual_var(rho)
+                if it == 22:   # the caller rewrites a factor: what was carried belongs to the old V
+                    V0 = s.be.get_mat(host.MAT_V, 0)
+                    s.be.set_mat(host.MAT_V, 0, 0.5 * V0)
+                    s.be.init_constr(host.PAIR_UV)
+                log.append((c, p, d, e))
+            out.append((log, [s.be.get_mat(host.MAT_U, k) for k in range(s.nblk)], [s.be.get_mat(host.MAT_V, k) for k in range(s.nblk)],
+                        s.be.get_vec(host.VEC_LAMBDA)))
+        finally:
+            s.close()
+    (la, Ua, Va, lama), (lb, Ub, Vb, lamb) = out
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert x[0] == y[0] and x[2] == y[2] and x[3] == y[3], (i, x, y)
+        assert abs(x[1] - y[1]) <= 1e-13 * abs(y[1]), (i, x[1], y[1])
+    for x, y in zip(Ua + Va + [lama], Ub + Vb + [lamb]):
+        assert np.array_equal(x, y)
+
+
 def test_rank_growth_rebuilds_the_teams(built):
     """AUG_RANK between two sweeps (data/lorads_solver.c:806-906): the plan follows the new ranks"""
     s = _session(common.instance_path("blk4x60"), True, phase1Tol=1e-2)
