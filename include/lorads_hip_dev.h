@@ -65,6 +65,12 @@ int lorads_hip_persist_stats(lorads_hip_ctx *ctx, int64_t stats[6]);
  * hand-over begins, 0 ...} (reads after synchronising the stream) */
 int lorads_hip_persist_stamps(lorads_hip_ctx *ctx, int32_t enable, uint64_t ticks[16]);
 
+/* phase 1, single rank, history length <= 2: setlbfgsHisTwo + LBFGSDirection + LBFGSDirectionUseGrad of an inner iteration
+ * (src_semi/lorads_alg/lorads_alm.c:230-391,469-489,540-560) as ONE launch of resident workgroups inside lorads_hip_alm_step
+ * (lorads_amd/csrc/hip/lbfgs_team.inc; LORADS_LBFGS_TEAM=0: launch by launch).
+ * stats = {launches so far, plan built (0/1), workgroups, pairs of doubles per thread and vector} */
+int lorads_hip_lbfgs_team_stats(lorads_hip_ctx *ctx, int64_t stats[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -470,6 +470,7 @@ struct Ring {
 };
 struct GraphCache; // captured launch chains (graph.inc)
 struct PersistPlan; // the one-launch ADMM iteration of Max-Cut-type cones (persist.inc)
+struct LTeamPlan;   // the one-launch L-BFGS history update + direction of phase 1 (lbfgs_team.inc)
 
 } // namespace
 
@@ -535,6 +536,8 @@ struct lorads_hip_ctx {
     bool opt_persist_l2 = true;              // granules / rows of workgroups verified to share an XCD go through its L2 (LORADS_PERSIST_L2=0: always written through)
     bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
     long long n_persist = 0;                 // ADMM iterations run that way
+    LTeamPlan *lteam = nullptr;              // phase 1: setlbfgsHisTwo + LBFGSDirection as one launch of resident workgroups (lbfgs_team.inc)
+    bool opt_lbfgs_team = true;              // (LORADS_LBFGS_TEAM=0: launch by launch)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
     // from the updated multipliers and stores them to lambda_alt, then the two vectors swap); sent off as k_dual_update
@@ -660,6 +663,7 @@ inline void persist_touch(lorads_hip_ctx *c); // (persist.inc: what the one-laun
 #include "build.inc"
 #include "sweep.inc"
 #include "persist.inc"
+#include "lbfgs_team.inc"
 
 } // namespace
 
@@ -761,6 +765,8 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_persist = !(getenv("LORADS_PERSIST") && getenv("LORADS_PERSIST")[0] == '0');
     c->opt_persist_l2 = !(getenv("LORADS_PERSIST_L2") && getenv("LORADS_PERSIST_L2")[0] == '0');
     c->opt_persist_carry = !(getenv("LORADS_PERSIST_CARRY") && getenv("LORADS_PERSIST_CARRY")[0] == '0');
+    c->lteam = new LTeamPlan();
+    c->opt_lbfgs_team = !(getenv("LORADS_LBFGS_TEAM") && getenv("LORADS_LBFGS_TEAM")[0] == '0');
     if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
         int dev = 0;
         char bus[64] = "0";
@@ -799,6 +805,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
     hipFree(c->ring_ab); hipFree(c->par); hipFree(c->seq_dev);
     graph_cache_free(c);
     if (c->persist) { c->persist->release(); delete c->persist; c->persist = nullptr; }
+    if (c->lteam) { c->lteam->release(); delete c->lteam; c->lteam = nullptr; }
     if (c->shared_gpu_fd >= 0) close(c->shared_gpu_fd);
     hipFree(c->seg_row0); hipFree(c->seg_vt0); hipFree(c->seg_vt_seg); hipFree(c->seg_vt_e0); hipFree(c->phase_done);
     if (c->h_ctrl) hipHostFree(c->h_ctrl);
@@ -1107,9 +1114,9 @@ int lorads_hip_set_lbfgs_his_two(lorads_hip_ctx *c, double tau) {
 // next iteration, and reads everything with ONE host synchronisation: out = {lagNormSq, err1, p1, p2, a, b, c, d}.
 // Same kernels in the same order as the slot-by-slot calls, so the results are identical; if the host leaves the
 // loop, the speculated direction is simply never used (it only touched D, q1/q2 and scratch).
-static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner) {
+static int enqueue_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, bool have_direction = false) {
     int np = 0;
-    if (lorads_hip_lbfgs_direction(c, inner) || enqueue_q12p12(c, &np)) return 1;
+    if ((!have_direction && lorads_hip_lbfgs_direction(c, inner)) || enqueue_q12p12(c, &np)) return 1;
     launch_linesearch(c, rho, np);
     // separable shards: the five m-vector sums and p1, p2 are this rank's parts -- one all-reduce of seven doubles
     return (c->ar && c->sep) ? allreduce_dev(c, c->scal + 16, 7) : 0;
@@ -1124,23 +1131,27 @@ int lorads_hip_alm_front(lorads_hip_ctx *c, double rho, int32_t inner, double ou
 }
 int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_inner, double out[8]) {
     Block *S1 = solo(c);
+    bool team = false;
     if (S1 && !c->ar && S1->nrow == c->m && c->m > 0 && !S1->dense_c && !S1->dense_a) {
         // one cone that sees every constraint (one rank: k_alm_tail forms 1/(y.s) from local sums): 7 launches for the whole second half
         Block &B = *S1;
         Ring &h = c->ring[c->head];
         const int gv = grid_lbfgs(c->all_elem);
         c->ls_np = 0;
+        // (the history update and the NEXT direction as one launch of resident workgroups, where that applies: lbfgs_team.inc)
+        team = lteam_ready(c, next_inner);
         LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum);
         WArgs wa{};
         wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
         sval(c, B.pu, true, W_ALM, wa, NOGUARD);
         const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
-        LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
+        if (team) { if (launch_lbfgs_team(c, tau, next_inner)) return 1; }
+        else LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
         pairdots(c, B.pa, c->R, c->R, B.r, B.T2, NOGUARD);
         const int nres = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 2048);
         LAUNCH(k_cv_res, nres, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.cv, B.row_idx, c->csum, c->b, c->lambda, part_slot(c, 8),
                part_slot(c, 9), NOGUARD);
-        LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), gv, c->ring_ab + 2 * c->head + 1, part_slot(c, 8),
+        LAUNCH(k_alm_tail, 1, part_slot(c, 0), glag, c->scal + 8, part_slot(c, 3), team ? 0 : gv, c->ring_ab + 2 * c->head + 1, part_slot(c, 8),
                part_slot(c, 9), nres, c->scal);
         c->head = (c->head + 1) % c->L;
     } else if (c->ar && c->sep && c->opt_gram) {
@@ -1163,9 +1174,14 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
                lorads_hip_set_lbfgs_his_two(c, tau) || enqueue_eval(c, LORADS_HIP_PAIR_RR, nullptr, false)) {
         return 1;
     }
-    if (next_inner >= 0 && enqueue_alm_front(c, rho, next_inner)) return 1;
+    if (next_inner >= 0 && enqueue_alm_front(c, rho, next_inner, team)) return 1;
     double s[23];
     if (read_scalars(c, 0, 23, s)) return 1;
+    if (team && s[7] != 0.0) {
+        c->lteam->failed = true; // (not again in this context)
+        return fail_msg("one-launch L-BFGS direction: the team of workgroups did not complete (are other processes holding the GPU's compute units?); "
+                        "LORADS_LBFGS_TEAM=0 selects the launch-by-launch form");
+    }
     out[0] = s[8];
     out[1] = std::sqrt(s[0]) / (1 + c->b_nrm1);
     out[2] = s[21]; out[3] = s[22];
@@ -1487,6 +1503,15 @@ int lorads_hip_persist_stats(lorads_hip_ctx *c, int64_t stats[6]) {
     stats[3] = ok ? c->persist->rows : 0;
     stats[4] = ok ? c->persist->ns : 0;
     stats[5] = ok ? (int64_t)c->persist->lds : 0;
+    return 0;
+}
+
+int lorads_hip_lbfgs_team_stats(lorads_hip_ctx *c, int64_t stats[4]) {
+    const bool ok = c->lteam && c->lteam->valid;
+    stats[0] = c->lteam ? c->lteam->launches : 0;
+    stats[1] = ok ? 1 : 0;
+    stats[2] = ok ? c->lteam->grid : 0;
+    stats[3] = ok ? c->lteam->np : 0;
     return 0;
 }
 

@@ -459,6 +459,14 @@ class Session:
         _check(lib.lorads_hip_persist_stats(ctx, out), "persist_stats")
         return dict(zip(["iterations", "available", "workgroups", "rows", "column_steps", "lds_bytes"], [int(out[i]) for i in range(6)]))
 
+    def hip_lbfgs_team_stats(self):
+        """phase 1's one-launch L-BFGS history update + direction (csrc/hip/lbfgs_team.inc): {launches, available, workgroups, pairs}"""
+        lib, ctx = self._hip()
+        out = (C.c_int64 * 4)()
+        lib.lorads_hip_lbfgs_team_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_lbfgs_team_stats(ctx, out), "lbfgs_team_stats")
+        return dict(zip(("launches", "available", "workgroups", "pairs"), [int(out[i]) for i in range(4)]))
+
     def hip_persist_stamps(self, enable=True):
         """100 MHz clock of cone 0's leader workgroup at the phase boundaries of the latest one-launch iteration (0: not taken)"""
         lib, ctx = self._hip()

@@ -40,10 +40,16 @@ LAUNCH_BY_LAUNCH_TESTS = {
     "test_fused_front_of_maxcut_cones_equals_the_separate_passes", "test_graph_replay_is_bitwise_the_launch_by_launch_iteration",
     "test_fused_paths_equal_the_step_by_step_forms",
 }
+# ... and the tests that compare phase 1's fused calls with the slot-by-slot calls bit for bit: the one-launch L-BFGS direction of
+# the fused step (csrc/hip/lbfgs_team.inc, its own A/B tests: tests/test_lbfgs_team.py) sums its dots in another order
+STAGE_BY_STAGE_TESTS = {"test_fused_alm_step_equals_separate_calls", "test_alm_front_and_step_function_level"}
 
 
 @pytest.fixture(autouse=True)
 def _launch_by_launch_form(request, monkeypatch):
-    if getattr(request.node, "originalname", request.node.name) in LAUNCH_BY_LAUNCH_TESTS:
+    name = getattr(request.node, "originalname", request.node.name)
+    if name in LAUNCH_BY_LAUNCH_TESTS:
         monkeypatch.setenv("LORADS_PERSIST", "0")
+    if name in STAGE_BY_STAGE_TESTS:
+        monkeypatch.setenv("LORADS_LBFGS_TEAM", "0")
     yield
