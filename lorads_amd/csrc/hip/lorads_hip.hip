@@ -538,6 +538,7 @@ struct lorads_hip_ctx {
     long long n_persist = 0;                 // ADMM iterations run that way
     LTeamPlan *lteam = nullptr;              // phase 1: setlbfgsHisTwo + LBFGSDirection as one launch of resident workgroups (lbfgs_team.inc)
     bool opt_lbfgs_team = true;              // (LORADS_LBFGS_TEAM=0: launch by launch)
+    bool opt_alm_fused_tail = true;          // ... and, behind it, shared passes for A(R R^T), q1, q2 and one closing workgroup (LORADS_ALM_FUSED_TAIL=0)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
     // from the updated multipliers and stores them to lambda_alt, then the two vectors swap); sent off as k_dual_update
@@ -767,6 +768,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_persist_carry = !(getenv("LORADS_PERSIST_CARRY") && getenv("LORADS_PERSIST_CARRY")[0] == '0');
     c->lteam = new LTeamPlan();
     c->opt_lbfgs_team = !(getenv("LORADS_LBFGS_TEAM") && getenv("LORADS_LBFGS_TEAM")[0] == '0');
+    c->opt_alm_fused_tail = !(getenv("LORADS_ALM_FUSED_TAIL") && getenv("LORADS_ALM_FUSED_TAIL")[0] == '0');
     if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
         int dev = 0;
         char bus[64] = "0";
@@ -1147,6 +1149,44 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
         if (team) { if (launch_lbfgs_team(c, tau, next_inner)) return 1; }
         else LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
+        if (team && c->use_publish && c->opt_alm_fused_tail && B.nc > 0 && B.pa.ne > 0 && lteam_scratch(c, (size_t)B.pa.ne) == 0) {
+            // the next direction exists already: the step's A(R R^T) and the next line search's q1, q2 share their passes, one
+            // workgroup closes the iteration and hands it over (lbfgs_team.inc) -- 5 launches where the forms below take 9
+            const Shape sh = shape_for(B.r);
+            const double *R = c->R + B.off, *D = c->U + B.off;
+            SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rrd<LG_, V2_, NS_>), nblocks_for((size_t)B.pa.ne, TPB / sh.lg), B.pa.ne, B.pa.erow,
+                                      B.pa.ecol, R, D, B.r, c->lteam->t0, B.T2, B.T));
+            B.t_uv_valid = false;
+            const int nls = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
+            LAUNCH(k_cv_res_rd, nls, B.nrow, B.a_ptr, B.a_e, B.a_val, (const double *)c->lteam->t0, (const double *)B.T2, (const double *)B.T,
+                   B.cv, B.row_idx, c->csum, c->q12, c->q12 + c->m, c->b, c->lambda, part_slot(c, 8), part_slot(c, 9), part_slot(c, 10), c->maxpart);
+            c->ls_np = nls;
+            const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
+            SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4), part_slot(c, 6)));
+            c->head = (c->head + 1) % c->L;
+            AlmCloseArgs ca{};
+            ca.lag_part = part_slot(c, 0); ca.nlag = glag;
+            ca.part_v = part_slot(c, 8); ca.part_d = part_slot(c, 9); ca.nres = nls;
+            ca.part_ls = part_slot(c, 10); ca.nls = nls; ca.pstride = c->maxpart;
+            ca.obj1 = part_slot(c, 4); ca.obj2 = part_slot(c, 6); ca.nobj = go;
+            ca.rinv = 1.0 / rho; ca.scal = c->scal; ca.q12_tail = c->q12 + 2 * (size_t)c->m;
+            flush_pending(c);
+            flush_final(c);
+            ++c->pub_seq;
+            LAUNCH(k_alm_close, 1, ca, (const unsigned long long *)c->ctrl, 23, (unsigned long long *)c->h_ctrl_dev, c->h_flag_dev, c->seq_dev);
+            if (wait_publish(c)) return 1;
+            const double *s = c->h_scal;
+            if (s[7] != 0.0) {
+                c->lteam->failed = true; // (not again in this context)
+                return fail_msg("one-launch L-BFGS direction: the team of workgroups did not complete (are other processes holding the GPU's compute units?); "
+                                "LORADS_LBFGS_TEAM=0 selects the launch-by-launch form");
+            }
+            out[0] = s[8];
+            out[1] = std::sqrt(s[0]) / (1 + c->b_nrm1);
+            out[2] = s[21]; out[3] = s[22];
+            quartic_coeffs(rho, s[21], s[22], s + 16, out + 4);
+            return 0;
+        }
         pairdots(c, B.pa, c->R, c->R, B.r, B.T2, NOGUARD);
         const int nres = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 2048);
         LAUNCH(k_cv_res, nres, B.nrow, B.a_ptr, B.a_e, B.a_val, B.T2, B.cv, B.row_idx, c->csum, c->b, c->lambda, part_slot(c, 8),

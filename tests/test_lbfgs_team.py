@@ -29,11 +29,16 @@ def _gen(name):
 
 
 def _session(path, team, **kw):
+    """team: True (the default: the one-launch direction and the shared passes behind it), "direction" (the one launch, then the
+    launch-by-launch tail: LORADS_ALM_FUSED_TAIL=0), False (LORADS_LBFGS_TEAM=0: everything launch by launch)"""
     os.environ["LORADS_LBFGS_TEAM"] = "1" if team else "0"
+    if team == "direction":
+        os.environ["LORADS_ALM_FUSED_TAIL"] = "0"
     try:
         return common.hip_session(path, **kw)
     finally:
         os.environ.pop("LORADS_LBFGS_TEAM", None)
+        os.environ.pop("LORADS_ALM_FUSED_TAIL", None)
 
 
 def _steps(path, team, iters, rho=0.7, **kw):
@@ -69,15 +74,16 @@ def test_one_launch_direction_equals_the_stage_by_stage_form(built, name, iters)
     ||Grad||^2, the residual) and R, the direction D, the gradient afterwards -- equal to the rounding of five dots summed in
     another order.  Iteration 0 -> 1 uses one history pair, later ones two."""
     path = common.instance_path(name)
-    (ra, ma, sa), (rb, mb, sb) = _steps(path, True, iters), _steps(path, False, iters)
+    (ra, ma, sa), (rb, mb, sb), (rc, mc, sc) = _steps(path, True, iters), _steps(path, False, iters), _steps(path, "direction", iters)
     assert sb["launches"] == 0, sb
     if sa["available"] == 0:
         pytest.skip("%s: not a context the one-launch form applies to (%s)" % (name, sa))
-    assert sa["launches"] == iters, sa
-    for i, (x, y) in enumerate(zip(ra, rb)):
-        assert _close(x, y, 1e-9), (name, i, x, y)
-    for x, y in zip(ma, mb):
-        assert _close(x, y, 1e-9), name
+    assert sa["launches"] == iters and sc["launches"] == iters, (sa, sc)
+    for r2, m2 in ((ra, ma), (rc, mc)):
+        for i, (x, y) in enumerate(zip(r2, rb)):
+            assert _close(x, y, 1e-9), (name, i, x, y)
+        for x, y in zip(m2, mb):
+            assert _close(x, y, 1e-9), name
     print(name, "ok:", sa)
 
 
