@@ -559,10 +559,12 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         s.hip_profile(1, 1 << 30)
     t0 = time.time()
     s.hip_sync()
+    n_l0 = s.hip_launch_count()
     t_p1 = time.perf_counter()
     s.alm()
     s.hip_sync()
     t_p1 = time.perf_counter() - t_p1
+    n_l_p1 = s.hip_launch_count() - n_l0
     s.alm_to_admm()
     res = s.results()
     rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
@@ -587,6 +589,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    n_l0 = s.hip_launch_count()
     t0 = time.perf_counter()
     err1, cg_iters, pobj, dobj = admm_steps(be, host, rho, err1, a.steps, s)
     s.hip_sync()
@@ -594,6 +597,7 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    n_l_timed = s.hip_launch_count() - n_l0
     prof = s.hip_profile_read()
     for k_ in ("matvec_launches", "speculation_misses", "cg_iters", "cg_solves", "sampled", "sampled_ms", "spmm_sampled", "spmm_sampled_ms"):
         prof[k_] -= prof0[k_]
@@ -705,7 +709,11 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
             # solver's own phase 1 on the GPU from the reference's start point to --phase1Tol 1e-2
             "phase1": None if not res["alm_inner"] else {
                 "inner_iters": int(res["alm_inner"]), "outer_iters": int(res["alm_outer"]), "seconds": t_p1,
-                "inner_iters_per_s": res["alm_inner"] / t_p1, "us_per_inner_iter": 1e6 * t_p1 / res["alm_inner"]},
+                "inner_iters_per_s": res["alm_inner"] / t_p1, "us_per_inner_iter": 1e6 * t_p1 / res["alm_inner"],
+                # (every kernel of phase 1 -- the outer iterations' own few included -- over its inner iterations)
+                "launches_per_inner_iter": n_l_p1 / res["alm_inner"],
+                "one_launch_direction": s.hip_lbfgs_team_stats()},
+            "launches_per_step": n_l_timed / max(a.steps, 1),
             "one_launch_iteration": None if not one_launch else {
                 "what": "every cone of Max-Cut type: one launch per ADMM iteration, teams of resident workgroups (csrc/hip/persist.inc)",
                 "workgroups": pstat["workgroups"], "rows_per_lane_group": pstat["rows"], "column_steps": pstat["column_steps"],
@@ -978,13 +986,13 @@ def main():
         if rank == 0:
             keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "scaling", "ranks_seen",
                     "scalar_exchange", "cg_iters_per_s", "cg_iters_per_admm_iter", "config", "roofline", "state", "parity_sharded",
-                    "one_launch_iteration", "phase1")
+                    "one_launch_iteration", "phase1", "launches_per_step")
             out["extra"] = [{k: ex[k] for k in keys if k in ex}]
     if rank == 0 and world == 1 and a.workload == "rand20000" and not a.no_extra:
         # the north-star target sentence is phrased on Max-Cut n = 20000, r = 40 (cfg3a): reported beside the headline
         keys = ("value", "unit", "ms_per_step", "ms_per_step_median", "cg_iters_per_s", "cg_iters_per_admm_iter", "config", "roofline",
                 "cpu_baseline", "state", "parity_full_size", "speedup_vs_cpu_1core", "speedup_vs_cpu_1core_cg_normalised", "phase1",
-                "one_launch_iteration")
+                "one_launch_iteration", "launches_per_step")
         ex = run_workload(a, "maxcut20000", torch, dist, device, world, rank, host, not a.no_cpu, tlr=4.0)
         out["extra"] = [{k: ex[k] for k in keys if k in ex}]
     if dist:

@@ -71,6 +71,10 @@ int lorads_hip_persist_stamps(lorads_hip_ctx *ctx, int32_t enable, uint64_t tick
  * stats = {launches so far, plan built (0/1), workgroups, pairs of doubles per thread and vector} */
 int lorads_hip_lbfgs_team_stats(lorads_hip_ctx *ctx, int64_t stats[4]);
 
+/* kernels this context has enqueued so far (its own launches; the direct hipLaunchKernelGGL sites of the scalar steps -- a handful
+ * per solve -- are not counted): bench.py divides the difference over a timed region by its steps */
+int lorads_hip_launch_count(lorads_hip_ctx *ctx, int64_t *n);
+
 #ifdef __cplusplus
 }
 #endif

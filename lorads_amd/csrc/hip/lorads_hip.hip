@@ -536,6 +536,7 @@ struct lorads_hip_ctx {
     bool opt_persist_l2 = true;              // granules / rows of workgroups verified to share an XCD go through its L2 (LORADS_PERSIST_L2=0: always written through)
     bool persist_stamps = false;             // team 0's leader leaves its phase times (lorads_hip_persist_stamps)
     long long n_persist = 0;                 // ADMM iterations run that way
+    long long n_launch = 0;                  // kernels enqueued through LAUNCH / the one-launch forms (lorads_hip_launch_count: bench.py's launches per step)
     LTeamPlan *lteam = nullptr;              // phase 1: setlbfgsHisTwo + LBFGSDirection as one launch of resident workgroups (lbfgs_team.inc)
     bool opt_lbfgs_team = true;              // (LORADS_LBFGS_TEAM=0: launch by launch)
     bool opt_alm_fused_tail = true;          // ... and, behind it, shared passes for A(R R^T), q1, q2 and one closing workgroup (LORADS_ALM_FUSED_TAIL=0)
@@ -1151,18 +1152,17 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         else LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));
         if (team && c->use_publish && c->opt_alm_fused_tail && B.nc > 0 && B.pa.ne > 0 && lteam_scratch(c, (size_t)B.pa.ne) == 0) {
             // the next direction exists already: the step's A(R R^T) and the next line search's q1, q2 share their passes, one
-            // workgroup closes the iteration and hands it over (lbfgs_team.inc) -- 5 launches where the forms below take 9
+            // workgroup closes the iteration and hands it over (lbfgs_team.inc) -- 3 launches where the forms below take 8
             const Shape sh = shape_for(B.r);
             const double *R = c->R + B.off, *D = c->U + B.off;
-            SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rrd<LG_, V2_, NS_>), nblocks_for((size_t)B.pa.ne, TPB / sh.lg), B.pa.ne, B.pa.erow,
-                                      B.pa.ecol, R, D, B.r, c->lteam->t0, B.T2, B.T));
+            const int g1 = nblocks_for((size_t)B.pa.ne, TPB / sh.lg), go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
+            SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rrd<LG_, V2_, NS_>), g1 + go, B.pa.ne, B.pa.erow, B.pa.ecol, R, D, B.r, c->lteam->t0, B.T2, B.T, g1,
+                                      B.nc, B.c_row, B.c_col, B.c_val, part_slot(c, 4), part_slot(c, 6)));
             B.t_uv_valid = false;
             const int nls = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
             LAUNCH(k_cv_res_rd, nls, B.nrow, B.a_ptr, B.a_e, B.a_val, (const double *)c->lteam->t0, (const double *)B.T2, (const double *)B.T,
                    B.cv, B.row_idx, c->csum, c->q12, c->q12 + c->m, c->b, c->lambda, part_slot(c, 8), part_slot(c, 9), part_slot(c, 10), c->maxpart);
             c->ls_np = nls;
-            const int go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
-            SHAPE_DISPATCH(sh, LAUNCH((k_obj_rd<LG_, V2_, NS_>), go, B.nc, B.c_row, B.c_col, B.c_val, R, D, B.r, part_slot(c, 4), part_slot(c, 6)));
             c->head = (c->head + 1) % c->L;
             AlmCloseArgs ca{};
             ca.lag_part = part_slot(c, 0); ca.nlag = glag;
@@ -1543,6 +1543,11 @@ int lorads_hip_persist_stats(lorads_hip_ctx *c, int64_t stats[6]) {
     stats[3] = ok ? c->persist->rows : 0;
     stats[4] = ok ? c->persist->ns : 0;
     stats[5] = ok ? (int64_t)c->persist->lds : 0;
+    return 0;
+}
+
+int lorads_hip_launch_count(lorads_hip_ctx *c, int64_t *n) {
+    *n = c->n_launch;
     return 0;
 }
 

@@ -459,6 +459,14 @@ class Session:
         _check(lib.lorads_hip_persist_stats(ctx, out), "persist_stats")
         return dict(zip(["iterations", "available", "workgroups", "rows", "column_steps", "lds_bytes"], [int(out[i]) for i in range(6)]))
 
+    def hip_launch_count(self):
+        """kernels this context has enqueued so far"""
+        lib, ctx = self._hip()
+        out = C.c_int64(0)
+        lib.lorads_hip_launch_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(lib.lorads_hip_launch_count(ctx, C.byref(out)), "launch_count")
+        return int(out.value)
+
     def hip_lbfgs_team_stats(self):
         """phase 1's one-launch L-BFGS history update + direction (csrc/hip/lbfgs_team.inc): {launches, available, workgroups, pairs}"""
         lib, ctx = self._hip()
