@@ -12,16 +12,21 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 
+# kernels only phase 1 launches: the ADMM part of a bench run starts behind the last of them (k_his_two*: the launch-by-launch inner
+# iteration; k_lbfgs_team / k_alm_close: round 4's fused one)
+PHASE1_MARKS = ("k_his_two", "k_lbfgs_team", "k_alm_close")
+
+
 def short(n):
     m = re.search(r"(k_\w+|__amd_\w+)", n)
     return m.group(1) if m else n[:40]
 
 
-last = max(i for i, r in enumerate(rows) if "k_his_two" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in PHASE1_MARKS))
 alm = len(sys.argv) > 2 and sys.argv[2] == "alm"
 adm = rows[:last + 1] if alm else rows[last + 1:]
 if alm:
-    print("inner iterations (k_his_two launches): %d" % sum(1 for r in adm if "k_his_two" in r["Kernel_Name"]))
+    print("inner iterations (k_his_two / k_lbfgs_team launches): %d" % sum(1 for r in adm if "k_his_two" in r["Kernel_Name"] or "k_lbfgs_team" in r["Kernel_Name"]))
 t0 = int(adm[0]["Start_Timestamp"])
 t1 = int(adm[-1]["End_Timestamp"])
 print(("ALM-part" if alm else "ADMM-part") + " kernels: %d  span %.3f ms" % (len(adm), (t1 - t0) / 1e6))
