@@ -874,6 +874,31 @@ def run_workload(a, workload, torch, dist, device, world, rank, host, with_cpu, 
         native[0].lorads_rccl_comm_destroy(native[1])
         s._rccl_native = None
     s.close()
+    if out is not None and world == 1 and out.get("phase1") and not os.environ.get("LORADS_BENCH_NO_PHASE1_RERUN"):
+        # The phase 1 above is the first GPU work of this process: the run-time loads every kernel on its first launch and the
+        # clocks come up from idle inside it (maxcut800: 33 ms for 127 inner iterations the first time, 8 ms every later time).
+        # The same phase 1 once more, in a fresh context, now that neither is the case -- what an inner iteration costs.
+        try:
+            s2 = host.Session.open(path)
+            s2.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
+            if workload == "matcomp50000" and os.environ.get("LORADS_BENCH_RANK_GROWTH") != "1":
+                s2.set_params(dyrankLevel=0)
+            s2.prepare(1, 0, separable=False)
+            s2.attach_hip()
+            s2.hip_sync()
+            n0 = s2.hip_launch_count()
+            t2 = time.perf_counter()
+            s2.alm()
+            s2.hip_sync()
+            t2 = time.perf_counter() - t2
+            r2 = s2.results()
+            if r2["alm_inner"]:
+                out["phase1"]["again_in_a_warm_process"] = {
+                    "inner_iters": int(r2["alm_inner"]), "seconds": t2, "us_per_inner_iter": 1e6 * t2 / r2["alm_inner"],
+                    "launches_per_inner_iter": (s2.hip_launch_count() - n0) / r2["alm_inner"]}
+            s2.close()
+        except Exception as e:  # noqa: BLE001
+            out["phase1"]["again_in_a_warm_process"] = {"error": str(e)}
     return out
 
 
