@@ -26,6 +26,7 @@ ab)
   python profiles/tools/stamp.py r04 $O
   ;;
 prof)
+  export LORADS_BENCH_NO_PHASE1_RERUN=1   # (the trace is cut into phase 1 / ADMM at the last phase-1 kernel)
   for w in rand20000 maxcut20000 matcomp50000 blk16x4000; do
     TL=4.0; [ $w = matcomp50000 ] && TL=5.5; [ $w = blk16x4000 ] && TL=2.0
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o p -- python3 bench.py $B --workload $w --times-log-rank $TL --steps 50 --warmup 5 > $O/kt_$w.log 2>&1
@@ -37,6 +38,7 @@ prof)
   python profiles/tools/stamp.py r04 $O
   ;;
 pmc)
+  export LORADS_BENCH_NO_PHASE1_RERUN=1
   for w in ${PMC_WORKLOADS:-rand20000 maxcut20000 blk16x4000 matcomp50000}; do
     TL=4.0; [ $w = matcomp50000 ] && TL=5.5; [ $w = blk16x4000 ] && TL=2.0
     for cn in FETCH_SIZE WRITE_SIZE; do
