@@ -702,6 +702,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     for (int k = 0; k < c->nb; ++k)
         if (build_block(c, c->blk[k], prob->blocks[k])) { lorads_hip_destroy(c); return 1; }
     if (build_merged(c, prob)) { lorads_hip_destroy(c); return 1; }
+    common_rank(c);
     refresh_merged(c);
     if (getenv("LORADS_HIP_VERBOSE"))
         fprintf(stderr, "lorads_hip: %d cone(s), merged view %s\n", c->nb, c->has_merged ? "on" : (c->merged_ok ? "off (ranks differ)" : "not applicable"));
@@ -1415,6 +1416,7 @@ int lorads_hip_resize_rank(lorads_hip_ctx *c, const int32_t *nr) {
     free_factors(c);
     invalidate_t(c);
     for (int k = 0; k < c->nb; ++k) { c->blk[k].rl = nr[k]; c->blk[k].r = dev_rank(c, nr[k], c->blk[k].is_lp); }
+    common_rank(c);
     refresh_merged(c);
     if (alloc_factors(c)) { for (auto p : old) hipFree(p); return 1; }
     double *now[4] = {c->R, c->U, c->V, c->G};

@@ -339,6 +339,9 @@ NAMED = {
     "matcomp50000": lambda: matcomp(25000, 25000, 200000, 10, 50000),  # cfg5
     # cfg4's shape with cones of unequal size, n_k in [2000, 6000] (unequal ranks: VERDICT r3 #6)
     "blk16var": lambda: block_diag([maxcut(2000 + 250 * k, 6 * (2000 + 250 * k), 4100 + k) for k in range(16)]),
+    # eight cones of the headline's kind (random sparse constraints), unequal sizes => unequal ranks: the lockstep sweep and the
+    # single-cone forms of phase 1 on cones that only share a device rank (csrc/hip/build.inc: common_rank)
+    "randblk8var": lambda: block_diag([randsparse(1500 + 250 * k, 400 + 60 * k, 5200 + k, c_edges=6 * (1500 + 250 * k)) for k in range(8)]),
 }
 
 
