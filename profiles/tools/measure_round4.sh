@@ -23,6 +23,7 @@ ab)
   bash profiles/tools/r04_carry_ab.sh 200 > $O/carry_ab.txt 2>&1; echo "carry ab rc=$?"
   bash profiles/tools/r04_lteam_ab.sh > $O/lteam_ab.txt 2>&1; echo "lteam ab rc=$?"
   python profiles/tools/r04_dinf_cost.py > $O/dinf_cost.txt 2>&1; echo "dinf rc=$?"
+  bash profiles/tools/r04_common_rank_ab.sh > $O/common_rank_ab.txt 2>&1; echo "common rank ab rc=$?"
   python profiles/tools/stamp.py r04 $O
   ;;
 prof)
