@@ -405,7 +405,6 @@ struct Block {
     double *Cfull = nullptr;  // npad x npad row-major, symmetric, zero padded
     double *Wd = nullptr;     // n x r result of C X
     double *Wpart = nullptr;  // split-K slabs of it
-    int ksplit = 1;
     int ksplit_b = 0;         // K split over workgroups of the second dense form (k_dense_cx_b; 0: not applicable)
     // DENSE constraint matrices (the reference's sdp_coeff_dense rule, data/lorads_sdp_data.c:820: nnz > 0.1 n(n+1)/2): kept
     // out of the sparse patterns (their rows of the constraint CSR are empty there) and stored as full symmetric npad x npad
@@ -559,7 +558,6 @@ struct lorads_hip_ctx {
     size_t dev_presolve_min = (size_t)1 << 15; // stored entries below which a pattern is built on the host (LORADS_DEV_PRESOLVE_MIN)
     long long n_dev_patterns = 0, n_checked_patterns = 0;
     bool opt_dense_cache = true; // dense constraint matrices: A_j V kept for the length of a CG solve (LORADS_DENSE_CACHE=0: nd + 1 GEMMs per application)
-    bool opt_dense_b = true;  // dense objective: C read as the MFMA B operand (k_dense_cx_b; LORADS_DENSE_B=0: k_dense_cx)
     bool opt_front_diag = true; // Max-Cut-type cones: the front forms its diagonal coefficients itself, no k_sval (LORADS_FRONT_DIAG=0)
     bool opt_eval_diag = true; // Max-Cut-type cones: k_eval_diag instead of k_average + k_pairdots + k_cv_res (LORADS_EVAL_DIAG=0)
     bool opt_fold_avg = true; // the sweep's last k_cg_update also forms R = (U + V) / 2 (LORADS_FOLD_AVG=0: k_average)
@@ -646,8 +644,7 @@ inline int grid1d(size_t len) {
     return (int)std::min<size_t>(std::max<size_t>(g, 1), 2048);
 }
 inline int grid_lbfgs(size_t len) {
-    static const int cap = getenv("LORADS_LBFGS_GRID") ? atoi(getenv("LORADS_LBFGS_GRID")) : 512;
-    return std::min(grid1d(len), cap);
+    return std::min(grid1d(len), 512);
 }
 // lanes per row/entry: 16-byte loads (2 columns per lane) when r is even and fits 8 lanes x 8 steps x 2
 inline bool use_v2(int r) { return (r % 2) == 0 && r <= 128; }
@@ -746,7 +743,6 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_tile_update = !(getenv("LORADS_TILE_UPDATE") && getenv("LORADS_TILE_UPDATE")[0] == '0');
     c->opt_eval_diag = !(getenv("LORADS_EVAL_DIAG") && getenv("LORADS_EVAL_DIAG")[0] == '0');
     c->opt_front_diag = !(getenv("LORADS_FRONT_DIAG") && getenv("LORADS_FRONT_DIAG")[0] == '0');
-    c->opt_dense_b = !(getenv("LORADS_DENSE_B") && getenv("LORADS_DENSE_B")[0] == '0');
     c->opt_dense_cache = !(getenv("LORADS_DENSE_CACHE") && getenv("LORADS_DENSE_CACHE")[0] == '0');
     c->opt_fuse_eval = !(getenv("LORADS_FUSE_EVAL") && getenv("LORADS_FUSE_EVAL")[0] == '0');
     c->opt_dense_rem = !(getenv("LORADS_DENSE_REM") && getenv("LORADS_DENSE_REM")[0] == '0');
