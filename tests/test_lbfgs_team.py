@@ -87,6 +87,43 @@ def test_one_launch_direction_equals_the_stage_by_stage_form(built, name, iters)
     print(name, "ok:", sa)
 
 
+@pytest.mark.parametrize("hist", [1, 3])
+def test_other_history_lengths(built, hist):
+    """lbfgsListLength 1 (the one launch with a single pair: the older node is the new one and is never read) and 3 (above what the
+    one launch holds: the stage-by-stage form runs, the switch changes nothing) -- 8 inner iterations on rand120, both settings"""
+    out = []
+    for team in (True, False):
+        os.environ["LORADS_LBFGS_TEAM"] = "1" if team else "0"
+        try:
+            s = host.Session.open(common.instance_path("rand120"))
+            s.set_params(verbose=0, lbfgsListLength=hist)
+            s.prepare(1, 0, separable=False)
+            s.attach_hip(lbfgs_len=hist)
+        finally:
+            os.environ.pop("LORADS_LBFGS_TEAM", None)
+        try:
+            be = s.be
+            rho = 0.7
+            be.init_constr(host.PAIR_RR)
+            be.alm_cal_grad(rho)
+            rec = []
+            front = be.alm_front(rho, 0)
+            for it in range(8):
+                p1, p2, coef = front
+                tau, _ = common.linesearch_tau(coef)
+                lag, err1, np1, np2, ncoef = be.alm_step(rho, tau, it + 1)
+                front = (np1, np2, ncoef)
+                rec.append([p1, p2, *coef, tau, lag, err1])
+            out.append((rec, be.get_mat(host.MAT_R, 0), s.hip_lbfgs_team_stats()))
+        finally:
+            s.close()
+    (ra, Ra, sa), (rb, Rb, sb) = out
+    assert sb["launches"] == 0 and sa["launches"] == (8 if hist <= 2 else 0), (sa, sb)
+    for i, (x, y) in enumerate(zip(ra, rb)):
+        assert _close(x, y, 1e-9), (hist, i, x, y)
+    assert _close(Ra, Rb, 1e-9)
+
+
 @pytest.mark.parametrize("name,params", [("maxcut100", dict(reoptLevel=0)), ("rand120", dict(reoptLevel=1, phase1Tol=1e-2)),
                                          ("theta30", dict(reoptLevel=1, phase1Tol=1e-2)), ("matcomp60", dict(reoptLevel=0, phase1Tol=1e-2))])
 def test_whole_solves_agree(built, name, params):
