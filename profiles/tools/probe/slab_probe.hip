@@ -17,31 +17,33 @@
 constexpr int TPB = 256;
 
 // 8 lanes per row, 32 rows per workgroup; U neighbours requested per trip
-template <int U>
+template <int U, int NST = 3>
 __global__ __launch_bounds__(TPB) void k_rowmajor(int n, int r, const int *__restrict__ ptr, const int *__restrict__ col,
                                                   const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ out) {
     const int lane = threadIdx.x & 7, p = blockIdx.x * (TPB / 8) + threadIdx.x / 8;
     if (p >= n) return;
-    double2 acc[3] = {{0, 0}, {0, 0}, {0, 0}};
+    double2 acc[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) acc[s] = double2{0, 0};
     const int e0 = ptr[p], e1 = ptr[p + 1];
     for (int e = e0; e < e1; e += U) {
-        int q[U]; double w[U]; double2 x[U][3];
+        int q[U]; double w[U]; double2 x[U][NST];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const int ee = e + u < e1 ? e + u : e0; q[u] = col[ee]; w[u] = e + u < e1 ? val[ee] : 0.0; }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int s = 0; s < NST; ++s) {
                 const int c = s * 16 + lane * 2;
                 x[u][s] = c < r ? *(const double2 *)(X + (size_t)q[u] * r + c) : double2{0, 0};
             }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { acc[s].x += w[u] * x[u][s].x; acc[s].y += w[u] * x[u][s].y; }
+            for (int s = 0; s < NST; ++s) { acc[s].x += w[u] * x[u][s].x; acc[s].y += w[u] * x[u][s].y; }
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < NST; ++s) {
         const int c = s * 16 + lane * 2;
         if (c < r) *(double2 *)(out + (size_t)p * r + c) = acc[s];
     }
@@ -93,7 +95,7 @@ template <class F> static double time_us(hipStream_t st, int reps, F f) {
 }
 
 int main(int argc, char **argv) {
-    const int n = argc > 1 ? atoi(argv[1]) : 20000, r = 40, deg = argc > 2 ? atoi(argv[2]) : 19;
+    const int n = argc > 1 ? atoi(argv[1]) : 20000, deg = argc > 2 ? atoi(argv[2]) : 19, r = argc > 3 ? atoi(argv[3]) : 40; // r = 40 or 64
     std::mt19937_64 g(1);
     std::vector<int> ptr(n + 1), col;
     std::vector<double> val;
@@ -129,11 +131,33 @@ int main(int argc, char **argv) {
     auto report = [&](const char *name, double us, double idx_mb) {
         printf("%-44s %8.2f us   %6.2f TB/s of rows   (indices + weights read: %.1f MB)\n", name, us, mb / us, idx_mb);
     };
+    auto slab_grid = [&](int S, int W) { const int rpb = (64 / (W / 2)) * 4; const int per = (n + rpb - 1) / rpb; return ((per + 8 / S - 1) / (8 / S)) * 8; };
     const int reps = 200;
     const int g_row = (n + TPB / 8 - 1) / (TPB / 8);
+    if (r == 64) { // a table far larger than one L2 (cfg5's regime: 480-byte rows of a 12-24 MB table): 4 slabs of 128 bytes
+        std::vector<double> X4b = slabbed(4);
+        HC(hipMemcpy(d_X4, X4b.data(), vb, hipMemcpyHostToDevice));
+        report("rowmajor r = 64, 4 neighbours per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_rowmajor<4, 4>), dim3(g_row), dim3(TPB), 0, st, n, r, d_ptr, d_col, d_val, d_X, d_o); }), ne * 12 / 1e6);
+        report("rowmajor r = 64, 8 neighbours per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_rowmajor<8, 4>), dim3(g_row), dim3(TPB), 0, st, n, r, d_ptr, d_col, d_val, d_X, d_o); }), ne * 12 / 1e6);
+        const int G = slab_grid(4, 16);
+        report("slab4 (128-byte pieces) XCD-affine, 8 per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_slab<4, 16, 8, true>), dim3(G), dim3(TPB), 0, st, n, d_ptr, d_col, d_val, d_X4, d_o4, d_mis); }), 4.0 * ne * 12 / 1e6);
+        const int G2 = ((n + 31) / 32 + 7) / 8 * 8 * 4;
+        report("slab4 (128-byte pieces), any XCD, 8 per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_slab<4, 16, 8, false>), dim3(G2), dim3(TPB), 0, st, n, d_ptr, d_col, d_val, d_X4, d_o4, d_mis); }), 4.0 * ne * 12 / 1e6);
+        std::vector<double> o((size_t)n * r), o4((size_t)n * r);
+        HC(hipMemcpy(o.data(), d_o, vb, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL((k_slab<4, 16, 8, true>), dim3(G), dim3(TPB), 0, st, n, d_ptr, d_col, d_val, d_X4, d_o4, d_mis);
+        HC(hipMemcpy(o4.data(), d_o4, vb, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int s = 0; s < 4; ++s) for (int q = 0; q < n; ++q) for (int c = 0; c < 16; ++c)
+            worst = std::fmax(worst, std::fabs(o4[((size_t)s * n + q) * 16 + c] - o[(size_t)q * r + s * 16 + c]));
+        printf("    slab4 against rowmajor: largest difference %.2e\n", worst);
+        int mis = 0;
+        HC(hipMemcpy(&mis, d_mis, sizeof(int), hipMemcpyDeviceToHost));
+        printf("workgroups whose XCC_ID was not blockIdx %% 8: %d\n", mis);
+        return 0;
+    }
     report("rowmajor, 4 neighbours per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_rowmajor<4>), dim3(g_row), dim3(TPB), 0, st, n, r, d_ptr, d_col, d_val, d_X, d_o); }), ne * 12 / 1e6);
     report("rowmajor, 8 neighbours per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_rowmajor<8>), dim3(g_row), dim3(TPB), 0, st, n, r, d_ptr, d_col, d_val, d_X, d_o); }), ne * 12 / 1e6);
-    auto slab_grid = [&](int S, int W) { const int rpb = (64 / (W / 2)) * 4; const int per = (n + rpb - 1) / rpb; return ((per + 8 / S - 1) / (8 / S)) * 8; };
     // slab4: 12 rows per wavefront, 48 per workgroup
     { const int G = slab_grid(4, 10);
       report("slab4 (80-byte pieces) XCD-affine, 8 per trip", time_us(st, reps, [&] { hipLaunchKernelGGL((k_slab<4, 10, 8, true>), dim3(G), dim3(TPB), 0, st, n, d_ptr, d_col, d_val, d_X4, d_o4, d_mis); }), 4.0 * ne * 12 / 1e6);
