@@ -538,6 +538,7 @@ struct lorads_hip_ctx {
     long long n_launch = 0;                  // kernels enqueued through LAUNCH / the one-launch forms (lorads_hip_launch_count: bench.py's launches per step)
     LTeamPlan *lteam = nullptr;              // phase 1: setlbfgsHisTwo + LBFGSDirection as one launch of resident workgroups (lbfgs_team.inc)
     bool opt_lbfgs_team = true;              // (LORADS_LBFGS_TEAM=0: launch by launch)
+    bool opt_alm_fold_cv = true;             // ... where every constraint has one entry the pattern pass does the constraint pass's work (LORADS_ALM_FOLD_CV=0)
     bool opt_alm_fused_tail = true;          // ... and, behind it, shared passes for A(R R^T), q1, q2 and one closing workgroup (LORADS_ALM_FUSED_TAIL=0)
     bool use_publish = true;
     // LORADSUpdateDualVar waiting for the first kernel of the next sweep (k_sval of the U-solve's front forms the weights
@@ -767,6 +768,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->lteam = new LTeamPlan();
     c->opt_lbfgs_team = !(getenv("LORADS_LBFGS_TEAM") && getenv("LORADS_LBFGS_TEAM")[0] == '0');
     c->opt_alm_fused_tail = !(getenv("LORADS_ALM_FUSED_TAIL") && getenv("LORADS_ALM_FUSED_TAIL")[0] == '0');
+    c->opt_alm_fold_cv = !(getenv("LORADS_ALM_FOLD_CV") && getenv("LORADS_ALM_FOLD_CV")[0] == '0');
     if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
         int dev = 0;
         char bus[64] = "0";
@@ -1153,12 +1155,25 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
             const Shape sh = shape_for(B.r);
             const double *R = c->R + B.off, *D = c->U + B.off;
             const int g1 = nblocks_for((size_t)B.pa.ne, TPB / sh.lg), go = std::min(nblocks_for((size_t)B.nc, TPB / sh.lg), 2048);
+            // cones whose constraints have ONE entry each (Max-Cut type, single-entry): the pattern pass does the constraints' bookkeeping too
+            // (up to 2048 workgroups' worth of entries: beyond that the nine block sums per workgroup and their partials cost more than
+            // the launch they save -- cfg5, 6250 workgroups: 191.7 -> 195.9 us per inner iteration)
+            const bool fold = c->opt_alm_fold_cv && (B.diag_only || B.entry_only) && B.na == B.nrow && B.pa.e_ptr && g1 <= std::min(c->maxpart, 2048);
+            CvFold cf{};
+            if (fold) {
+                cf.e_ptr = B.pa.e_ptr; cf.e_con = B.pa.e_con; cf.e_val = B.pa.e_val; cf.row_idx = B.row_idx; cf.cv = B.cv; cf.csum = c->csum;
+                cf.q1 = c->q12; cf.q2 = c->q12 + c->m; cf.b = c->b; cf.lambda = c->lambda; cf.part_v = part_slot(c, 8); cf.part_d = part_slot(c, 9);
+                cf.part_ls = part_slot(c, 10); cf.pstride = c->maxpart;
+            }
             SHAPE_DISPATCH(sh, LAUNCH((k_pairdots_rrd<LG_, V2_, NS_>), g1 + go, B.pa.ne, B.pa.erow, B.pa.ecol, R, D, B.r, c->lteam->t0, B.T2, B.T, g1,
-                                      B.nc, B.c_row, B.c_col, B.c_val, part_slot(c, 4), part_slot(c, 6)));
+                                      B.nc, B.c_row, B.c_col, B.c_val, part_slot(c, 4), part_slot(c, 6), cf));
             B.t_uv_valid = false;
-            const int nls = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
-            LAUNCH(k_cv_res_rd, nls, B.nrow, B.a_ptr, B.a_e, B.a_val, (const double *)c->lteam->t0, (const double *)B.T2, (const double *)B.T,
-                   B.cv, B.row_idx, c->csum, c->q12, c->q12 + c->m, c->b, c->lambda, part_slot(c, 8), part_slot(c, 9), part_slot(c, 10), c->maxpart);
+            int nls = g1;
+            if (!fold) {
+                nls = std::min(nblocks_for((size_t)B.nrow, TPB / 8), 1024);
+                LAUNCH(k_cv_res_rd, nls, B.nrow, B.a_ptr, B.a_e, B.a_val, (const double *)c->lteam->t0, (const double *)B.T2, (const double *)B.T,
+                       B.cv, B.row_idx, c->csum, c->q12, c->q12 + c->m, c->b, c->lambda, part_slot(c, 8), part_slot(c, 9), part_slot(c, 10), c->maxpart);
+            }
             c->ls_np = nls;
             c->head = (c->head + 1) % c->L;
             AlmCloseArgs ca{};

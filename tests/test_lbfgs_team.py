@@ -34,11 +34,14 @@ def _session(path, team, **kw):
     os.environ["LORADS_LBFGS_TEAM"] = "1" if team else "0"
     if team == "direction":
         os.environ["LORADS_ALM_FUSED_TAIL"] = "0"
+    if team == "nofold":   # (the shared passes, but the constraints' bookkeeping as a pass of its own: LORADS_ALM_FOLD_CV=0)
+        os.environ["LORADS_ALM_FOLD_CV"] = "0"
     try:
         return common.hip_session(path, **kw)
     finally:
         os.environ.pop("LORADS_LBFGS_TEAM", None)
         os.environ.pop("LORADS_ALM_FUSED_TAIL", None)
+        os.environ.pop("LORADS_ALM_FOLD_CV", None)
 
 
 def _steps(path, team, iters, rho=0.7, **kw):
@@ -75,11 +78,12 @@ def test_one_launch_direction_equals_the_stage_by_stage_form(built, name, iters)
     another order.  Iteration 0 -> 1 uses one history pair, later ones two."""
     path = common.instance_path(name)
     (ra, ma, sa), (rb, mb, sb), (rc, mc, sc) = _steps(path, True, iters), _steps(path, False, iters), _steps(path, "direction", iters)
+    rd, md, sd = _steps(path, "nofold", iters)
     assert sb["launches"] == 0, sb
     if sa["available"] == 0:
         pytest.skip("%s: not a context the one-launch form applies to (%s)" % (name, sa))
-    assert sa["launches"] == iters and sc["launches"] == iters, (sa, sc)
-    for r2, m2 in ((ra, ma), (rc, mc)):
+    assert sa["launches"] == iters and sc["launches"] == iters and sd["launches"] == iters, (sa, sc, sd)
+    for r2, m2 in ((ra, ma), (rc, mc), (rd, md)):
         for i, (x, y) in enumerate(zip(r2, rb)):
             assert _close(x, y, 1e-9), (name, i, x, y)
         for x, y in zip(m2, mb):
