@@ -60,9 +60,9 @@ def test_every_rank_sees_the_same_sums(world):
     ps = [ctx.Process(target=_worker, args=(r, world, name, calls, q, False)) for r in range(world)]
     for p in ps:
         p.start()
-    res = dict((r, (rc, out)) for r, rc, out in [q.get(timeout=120) for _ in range(world)])
+    res = dict((r, (rc, out)) for r, rc, out in [q.get(timeout=600) for _ in range(world)])
     for p in ps:
-        p.join(timeout=30)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(res[r][0] == 0 and len(res[r][1]) == calls for r in range(world))
     for r in range(1, world):
@@ -88,9 +88,9 @@ def test_a_rank_that_never_arrives_ends_the_wait(monkeypatch):
     t0 = time.time()
     for p in ps:
         p.start()
-    res = dict((r, (rc, out)) for r, rc, out in [q.get(timeout=60) for _ in range(world)])
+    res = dict((r, (rc, out)) for r, rc, out in [q.get(timeout=600) for _ in range(world)])
     for p in ps:
-        p.join(timeout=30)
+        p.join(timeout=120)
     assert time.time() - t0 < 40
     assert res[world - 1][0] == 0 and len(res[world - 1][1]) == calls - 1
     for r in range(world - 1):
@@ -140,8 +140,8 @@ def test_a_leftover_segment_of_a_dead_run_is_not_attached_to(monkeypatch, reques
     dead = ctx.Process(target=_leftover_maker, args=(name, 2, q))
     dead.start()
     request.addfinalizer(lambda: os.path.exists("/dev/shm" + name) and os.unlink("/dev/shm" + name))
-    assert q.get(timeout=30) == 0
-    dead.join(timeout=30)
+    assert q.get(timeout=300) == 0
+    dead.join(timeout=120)
     assert os.path.exists("/dev/shm" + name)          # the leftover is there, magic word and all
     r0 = ctx.Process(target=_late_rank0, args=(name, 2, 1.0, q))
     r0.start()                                         # the new rank 0 arrives a second AFTER rank 1 has started to open
@@ -150,7 +150,7 @@ def test_a_leftover_segment_of_a_dead_run_is_not_attached_to(monkeypatch, reques
     assert lib.lrd_shmx_open(name.encode(), 2, 1, C.byref(h)) == 0
     v = (C.c_double * 1)(2.0)
     assert lib.lrd_shmx_allreduce(h, v, 1) == 0 and v[0] == 3.0    # the two ranks met on the SAME (fresh) segment
-    tag, rc, rc2, got = q.get(timeout=30)
+    tag, rc, rc2, got = q.get(timeout=300)
     assert (rc, rc2, got) == (0, 0, 3.0)
     lib.lrd_shmx_close(h)
-    r0.join(timeout=30)
+    r0.join(timeout=120)
