@@ -26,7 +26,13 @@ for fam in ("rand", "maxcut"):
         s.set_params(verbose=0, timesLogRank=tlr, phase1Tol=1e-2, reoptLevel=0)
         s.prepare(1, 0)
         s.attach_hip()
+        s.hip_sync()
+        n_l0 = s.hip_launch_count()
+        t_p1 = time.perf_counter()
         s.alm()
+        s.hip_sync()
+        t_p1 = time.perf_counter() - t_p1
+        n_l_p1 = s.hip_launch_count() - n_l0
         s.alm_to_admm()
         res = s.results()
         rho = min(res["admm_rho"] if res["admm_rho"] > 0 else res["alm_rho"], 5000.0)
@@ -36,15 +42,19 @@ for fam in ("rand", "maxcut"):
         err1 = be.update_dimacs(host.PAIR_UV)
         err1, _, _, _ = bench.admm_steps(be, host, rho, err1, 10, s)
         s.hip_sync()
+        n_l0 = s.hip_launch_count()
         t0 = time.perf_counter()
         err1, cg, _, _ = bench.admm_steps(be, host, rho, err1, steps, s)
         s.hip_sync()
         el = time.perf_counter() - t0
+        n_l = s.hip_launch_count() - n_l0
         op_ms = s.hip_time_operator(200) / 200
         mv, _ = s.hip_algorithmic_bytes(0)
         info = s.block_info(0)
         gs = s.hip_graph_stats()
-        print("%-10s %7d %4d %9d | %9.1f %10.1f %7.4f | %8.2f %9.2f %6.1f | %s | graph replays %d captures %d" %
+        inner = max(res["alm_inner"], 1)
+        print("%-10s %7d %4d %9d | %9.1f %10.1f %7.4f | %8.2f %9.2f %6.1f | %s | graph replays %d captures %d | launches per ADMM iteration %.1f | "
+              "phase 1: %.1f us and %.1f launches per inner iteration (%d)" %
               (fam, n, info["rank"], info["nrow"], steps / el, cg / el, 1e3 * el / steps, 1e3 * op_ms, mv / 1e6, 100 * mv / (op_ms * 1e-3) / 8e12,
-               s.hip_operator_kind(0), gs["replayed"], gs["captured"]), flush=True)
+               s.hip_operator_kind(0), gs["replayed"], gs["captured"], n_l / steps, 1e6 * t_p1 / inner, n_l_p1 / inner, int(inner)), flush=True)
         s.close()
