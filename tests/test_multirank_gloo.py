@@ -59,7 +59,7 @@ def _worker(rank, world, port, name, params, q, separable=False):
     ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), False),
     # the separable form (what bench.py --gpus N runs): every rank on the sub-problem over its own constraints, scalars only
     # through the hook -- the host's cut (lrd_problem_localize) and control flow with the checker's restatement of the mode
-    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), True), ("mix4", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), True),
+    ("blk4x60", dict(reoptLevel=1, phase1Tol=1e-2), True), ("mix4", dict(reoptLevel=1, phase1Tol=1e-1, phase2Tol=1e-7), True),
     ("coupled3x70", dict(reoptLevel=1, phase1Tol=1e-2, phase2Tol=1e-7), True)])   # (asked for, not separable: stays m-vector)
 def test_two_ranks_match_single_process(name, params, separable):
     from tests import common
@@ -94,7 +94,8 @@ def test_two_ranks_match_single_process(name, params, separable):
     for k in ("pObj", "dObj", "constrVio1", "pdGap", "admm_iter", "alm_inner"):
         assert a[k] == b[k], (k, a[k], b[k])
     if name == "mix4":
-        # separable, but a long phase 1 (11 000 inner iterations): the sums' orders differ -> converged objectives
+        # separable, but a long phase 1 (3600 inner iterations over the reopt rounds; 11 700 at phase1Tol 1e-2, which a host with
+        # stolen vCPUs took 4 minutes of tiny collectives for): the sums' orders differ -> converged objectives
         assert abs(a["pObj"] - ref["pObj"]) <= 2e-6 * (1 + abs(ref["pObj"]))
         assert abs(a["dObj"] - ref["dObj"]) <= 2e-6 * (1 + abs(ref["dObj"]))
         assert a["constrVio1"] <= 1e-6
