@@ -6,7 +6,7 @@ Corrections applied (MI355X_MICROARCH.md, HBM section): counters are in KiB; on 
 half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact.  Infinity-Cache hits are
 counted by these fabric-side counters, so "traffic" is L2-miss traffic, an upper bound of HBM bytes.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <workload>
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <workload> [alm]
 """
 import collections
 import csv
@@ -26,11 +26,14 @@ def short(n):
     return m.group(1) if m else n[:40]
 
 
+ALM = len(sys.argv) > 5 and sys.argv[5] == "alm"   # the phase-1 part of the run (up to its last kernel) instead of the ADMM part
+
+
 def per_kernel(path, counter):
     rows = list(csv.DictReader(open(path)))
     last = max(i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in PHASE1_MARKS))
     agg = collections.defaultdict(list)
-    for r in rows[last + 1:]:
+    for r in (rows[:last + 1] if ALM else rows[last + 1:]):
         if r["Counter_Name"] == counter:
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return agg
@@ -38,7 +41,7 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"workload": sys.argv[4], "unit": "bytes per launch", "corrections": "KiB->bytes; FETCH_SIZE x2 (gfx950); WRITE_SIZE x1",
+out = {"workload": sys.argv[4], "part": "phase 1 (BM / ALM inner iterations)" if ALM else "ADMM iterations", "unit": "bytes per launch", "corrections": "KiB->bytes; FETCH_SIZE x2 (gfx950); WRITE_SIZE x1",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, [0.0])

@@ -12,6 +12,7 @@ for w in rand20000 maxcut20000 matcomp50000 blk16x4000; do
   cp $O/${w}_kernel_stats.csv profiles/r04_${w}_kernel_stats.csv
   cp $O/pmc_$w.json profiles/r04_pmc_$w.json
 done
+for w in rand20000 matcomp50000; do [ -f $O/pmc_alm_$w.json ] && cp $O/pmc_alm_$w.json profiles/r04_pmc_alm_$w.json; done
 cp $O/persist_phase_times.txt profiles/r04_persist_phase_times.txt
 cp $O/persist_ab.txt profiles/r04_persist_ab.txt
 cp $O/dinf_cost.txt profiles/r04_dinf_cost.txt
