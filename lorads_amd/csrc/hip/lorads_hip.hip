@@ -388,6 +388,12 @@ struct Block {
     size_t off = 0;           // offset of this cone in the flat factor arrays
     int *row_idx = nullptr;
     bool row_idx_identity = false; // row_idx[i] == i for every local constraint (a cone that sees all constraints in order)
+    // Every entry of the union pattern that a constraint touches is touched by exactly ONE (sv_direct): the coefficient of such an entry
+    // is cbase + weight a of that one constraint, so whoever holds the constraint's weight can write it -- phase 1's k_alm_update does,
+    // and k_sval is not launched (constraint -> its entries of the union pattern, CSR: sv_ptr, sv_e, sv_a)
+    bool sv_direct = false;
+    int *sv_ptr = nullptr, *sv_e = nullptr;
+    double *sv_a = nullptr;
     int *a_ptr = nullptr, *a_e = nullptr;  // constraint CSR over the A-pattern
     double *a_val = nullptr;
     Pattern pa, pu;
@@ -538,6 +544,7 @@ struct lorads_hip_ctx {
     long long n_launch = 0;                  // kernels enqueued through LAUNCH / the one-launch forms (lorads_hip_launch_count: bench.py's launches per step)
     LTeamPlan *lteam = nullptr;              // phase 1: setlbfgsHisTwo + LBFGSDirection as one launch of resident workgroups (lbfgs_team.inc)
     bool opt_lbfgs_team = true;              // (LORADS_LBFGS_TEAM=0: launch by launch)
+    bool opt_alm_sval_direct = true;         // ... and k_alm_update writes the entries' coefficients where Block::sv_direct holds (LORADS_ALM_SVAL_DIRECT=0: k_sval)
     bool opt_alm_fold_cv = true;             // ... where every constraint has one entry the pattern pass does the constraint pass's work (LORADS_ALM_FOLD_CV=0)
     bool opt_alm_fused_tail = true;          // ... and, behind it, shared passes for A(R R^T), q1, q2 and one closing workgroup (LORADS_ALM_FUSED_TAIL=0)
     bool use_publish = true;
@@ -769,6 +776,7 @@ int lorads_hip_create(const lorads_hip_problem *prob, lorads_hip_ctx **out) {
     c->opt_lbfgs_team = !(getenv("LORADS_LBFGS_TEAM") && getenv("LORADS_LBFGS_TEAM")[0] == '0');
     c->opt_alm_fused_tail = !(getenv("LORADS_ALM_FUSED_TAIL") && getenv("LORADS_ALM_FUSED_TAIL")[0] == '0');
     c->opt_alm_fold_cv = !(getenv("LORADS_ALM_FOLD_CV") && getenv("LORADS_ALM_FOLD_CV")[0] == '0');
+    c->opt_alm_sval_direct = !(getenv("LORADS_ALM_SVAL_DIRECT") && getenv("LORADS_ALM_SVAL_DIRECT")[0] == '0');
     if (getenv("LORADS_SHARED_GPU") && getenv("LORADS_SHARED_GPU")[0] == '1') {
         int dev = 0;
         char bus[64] = "0";
@@ -794,6 +802,7 @@ void lorads_hip_destroy(lorads_hip_ctx *c) {
         Block &B = *bp;
         B.pa.release(); B.pu.release();
         if (!B.cv_borrowed) hipFree(B.cv);
+        hipFree(B.sv_ptr); hipFree(B.sv_e); hipFree(B.sv_a);
         hipFree(B.row_idx); hipFree(B.a_ptr); hipFree(B.a_e); hipFree(B.a_val); hipFree(B.Cfull); hipFree(B.T); hipFree(B.T2); hipFree(B.wtmp);
         hipFree(B.c_row); hipFree(B.c_col); hipFree(B.c_val); hipFree(B.gdiag); hipFree(B.diag_row); hipFree(B.diag_a); hipFree(B.rc_con); hipFree(B.gentry); hipFree(B.bip_rows[0]); hipFree(B.bip_rows[1]); hipFree(B.bip_we); hipFree(B.ca_row); hipFree(B.ca_col); hipFree(B.ca_val); hipFree(B.cadj_ptr); hipFree(B.cadj_col); hipFree(B.cadj_con); hipFree(B.cadj_a); hipFree(B.cell_col); hipFree(B.cell_con); hipFree(B.cell_a);
         hipFree(B.d_con); hipFree(B.Adense); hipFree(B.Sfull); hipFree(B.d_mu); hipFree(B.fc_ptr); hipFree(B.fc_col); hipFree(B.fc_val); hipFree(B.cell_dst); hipFree(B.cadj_dst); hipFree(B.w_contrib);
@@ -1142,10 +1151,17 @@ int lorads_hip_alm_step(lorads_hip_ctx *c, double rho, double tau, int32_t next_
         c->ls_np = 0;
         // (the history update and the NEXT direction as one launch of resident workgroups, where that applies: lbfgs_team.inc)
         team = lteam_ready(c, next_inner);
-        LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum);
-        WArgs wa{};
-        wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
-        sval(c, B.pu, true, W_ALM, wa, NOGUARD);
+        SvDirect sd{};
+        if (c->opt_alm_sval_direct && B.sv_direct && B.pu.cbase && B.nrow == c->m) {
+            sd.ptr = B.sv_ptr; sd.e = B.sv_e; sd.a = B.sv_a; sd.cbase = B.pu.cbase; sd.S = B.pu.S; sd.row_idx = B.row_idx; sd.b = c->b; sd.lambda = c->lambda;
+            sd.rho = rho; sd.nrow = B.nrow;
+        }
+        LAUNCH(k_alm_update, gv, c->all_elem, tau, c->G, c->U, h.y, c->R, c->m, c->q12, c->q12 + c->m, c->csum, sd);
+        if (!sd.ptr) {
+            WArgs wa{};
+            wa.csum = c->csum; wa.b = c->b; wa.lambda = c->lambda; wa.row_idx = B.row_idx_identity ? nullptr : B.row_idx; wa.rho = rho;
+            sval(c, B.pu, true, W_ALM, wa, NOGUARD);
+        }
         const int glag = spmm(c, B, B.pu, c->R, OP_GRAD, nullptr, nullptr, rho, c->G, part_slot(c, 0), NOGUARD);
         if (team) { if (launch_lbfgs_team(c, tau, next_inner)) return 1; }
         else LAUNCH(k_his_two_dot, gv, c->all_elem, tau, c->U, c->G, h.s, h.y, part_slot(c, 3));

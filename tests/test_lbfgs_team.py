@@ -36,12 +36,15 @@ def _session(path, team, **kw):
         os.environ["LORADS_ALM_FUSED_TAIL"] = "0"
     if team == "nofold":   # (the shared passes, but the constraints' bookkeeping as a pass of its own: LORADS_ALM_FOLD_CV=0)
         os.environ["LORADS_ALM_FOLD_CV"] = "0"
+    if team == "sval":     # (the entries' coefficients by k_sval instead of by k_alm_update: LORADS_ALM_SVAL_DIRECT=0)
+        os.environ["LORADS_ALM_SVAL_DIRECT"] = "0"
     try:
         return common.hip_session(path, **kw)
     finally:
         os.environ.pop("LORADS_LBFGS_TEAM", None)
         os.environ.pop("LORADS_ALM_FUSED_TAIL", None)
         os.environ.pop("LORADS_ALM_FOLD_CV", None)
+        os.environ.pop("LORADS_ALM_SVAL_DIRECT", None)
 
 
 def _steps(path, team, iters, rho=0.7, **kw):
@@ -79,10 +82,13 @@ def test_one_launch_direction_equals_the_stage_by_stage_form(built, name, iters)
     path = common.instance_path(name)
     (ra, ma, sa), (rb, mb, sb), (rc, mc, sc) = _steps(path, True, iters), _steps(path, False, iters), _steps(path, "direction", iters)
     rd, md, sd = _steps(path, "nofold", iters)
+    re_, me, se = _steps(path, "sval", iters)
     assert sb["launches"] == 0, sb
     if sa["available"] == 0:
         pytest.skip("%s: not a context the one-launch form applies to (%s)" % (name, sa))
     assert sa["launches"] == iters and sc["launches"] == iters and sd["launches"] == iters, (sa, sc, sd)
+    # (the coefficients k_alm_update writes are the ones k_sval would: the same numbers bit for bit)
+    assert ra == re_ and all(np.array_equal(x, y) for x, y in zip(ma, me)), name
     for r2, m2 in ((ra, ma), (rc, mc), (rd, md)):
         for i, (x, y) in enumerate(zip(r2, rb)):
             assert _close(x, y, 1e-9), (name, i, x, y)
