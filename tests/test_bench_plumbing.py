@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from tests import common
 
@@ -61,3 +62,39 @@ def test_kernel_profile_is_the_default_runs(tmp_path, monkeypatch):
     assert src.endswith("r07_rand20000_kernel_stats.csv") and np.isclose(ms, 0.014)
     ms, src = bench.rocprof_from_profiles("rand20000", "k_front_cw")
     assert np.isclose(ms, 0.027)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_line_keeps_the_contract_end_to_end():
+    """`python bench.py` as the driver runs it, on a small workload: ONE JSON line on stdout with the contract's keys, the two objects
+    the tier asks for (`roofline`, `cpu_baseline`), and round 4's `phase1` / `launches_per_step`"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "maxcut800",
+                        "--times-log-rank", "2.0", "--cpu-budget", "3", "--no-extra", "--roofline-samples", "20"],
+                       capture_output=True, text=True, timeout=550, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "phase1", "launches_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert d["launches_per_step"] == 1.0      # (a Max-Cut-type context: the whole iteration is one launch)
+    p1 = d["phase1"]
+    assert p1["inner_iters"] > 0 and p1["us_per_inner_iter"] > 0 and p1["launches_per_inner_iter"] < 12
+    assert p1["again_in_a_warm_process"]["inner_iters"] == p1["inner_iters"]
