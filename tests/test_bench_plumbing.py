@@ -98,3 +98,26 @@ def test_bench_line_keeps_the_contract_end_to_end():
     p1 = d["phase1"]
     assert p1["inner_iters"] > 0 and p1["us_per_inner_iter"] > 0 and p1["launches_per_inner_iter"] < 12
     assert p1["again_in_a_warm_process"]["inner_iters"] == p1["inner_iters"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("args,scaling", [(["--workload", "rand120"], "weak"), (["--scaling", "strong", "--workload", "blk4x60"], "strong")])
+def test_bench_line_with_two_ranks_on_one_card(args, scaling):
+    """`python bench.py --gpus 2` starting its own ranks (two processes on the one card, gloo as the hook's transport): the line names
+    two ranks SEEN through the library's hook, carries the sharded-parity block, and the process exits 0 only because both hold"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LORADS_DIST_BACKEND="gloo", LORADS_FORCE_DEVICE="0", MASTER_PORT="29611")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu", "--no-extra",
+                        "--roofline-samples", "0"] + args, capture_output=True, text=True, timeout=800, cwd=root, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == scaling, (d["n_gpus"], d["ranks_seen"], d["scaling"])
+    ps = d["parity_sharded"]
+    assert ps["ok"] is True and ps["cg_iters_sharded"] == ps["cg_iters_single_rank"] and ps["pObj_rel_diff"] <= 1e-10, ps
+    assert d["value"] > 0 and d["scalar_exchange"] is not None
